@@ -1,0 +1,133 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/c2m_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under c2-matching_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libc2m_oracle.so")
+_lib = None
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_int = ctypes.c_int
+
+
+def build(force=False):
+    """Compile the oracle with gcc (building the checker is not using it)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "c2m_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libc2m_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        L.c2m_oracle_feature_normalize.argtypes = [_f32p, _int, _int, _f32p]
+        L.c2m_oracle_patch_norms.argtypes = [_f32p, _int, _int, _int, _int, _int, _f32p]
+        L.c2m_oracle_feature_match_index.argtypes = [_f32p, _f32p] + [_int] * 12 + [_i64p, _f32p]
+        L.c2m_oracle_build_pre_offsets.argtypes = [_i64p, _int, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.c2m_oracle_dcn_v2_forward.argtypes = [_f32p] * 5 + [_int] * 14 + [_f32p]
+        L.c2m_oracle_dcn_v2_backward.argtypes = [_f32p] * 6 + [_int] * 14 + [_f32p] * 5
+        L.c2m_oracle_set_num_threads.argtypes = [_int]
+        _lib = L
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def num_threads():
+    return lib().c2m_oracle_num_threads()
+
+
+def set_num_threads(n):
+    lib().c2m_oracle_set_num_threads(int(n))
+
+
+def feature_normalize(x):
+    """x: (C,H,W) -> per-pixel channel-normalised copy (corres_generation_arch.py:56-58)."""
+    x = _f32(x)
+    c = x.shape[0]
+    out = np.empty_like(x)
+    _chk(lib().c2m_oracle_feature_normalize(x, c, x.size // c, out), "feature_normalize")
+    return out
+
+
+def patch_norms(x, patch_size=3, stride=1):
+    x = _f32(x)
+    c, h, w = x.shape
+    hp, wp = (h - patch_size) // stride + 1, (w - patch_size) // stride + 1
+    out = np.empty((hp, wp), np.float32)
+    _chk(lib().c2m_oracle_patch_norms(x, c, h, w, patch_size, stride, out), "patch_norms")
+    return out
+
+
+def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
+                        norm_input=False, qrows=None):
+    """Same contract as ref_map_util.py:26-86 on numpy arrays: returns (max_idx int64, max_val float32)."""
+    fi, fr = _f32(feat_input), _f32(feat_ref)
+    c, hq, wq = fi.shape
+    c2, hr, wr = fr.shape
+    assert c == c2
+    hqp, wqp = (hq - patch_size) // input_stride + 1, (wq - patch_size) // input_stride + 1
+    idx = np.zeros((hqp, wqp), np.int64)
+    val = np.zeros((hqp, wqp), np.float32)
+    q0, q1 = (0, hqp) if qrows is None else qrows
+    _chk(lib().c2m_oracle_feature_match_index(fi, fr, c, hq, wq, hr, wr, patch_size, input_stride, ref_stride,
+                                              int(bool(is_norm)), int(bool(norm_input)), q0, q1, idx, val),
+         "feature_match_index")
+    return idx, val
+
+
+def build_pre_offsets(max_idx, h, w):
+    """max_idx: (h-2, w-2) int64 of one sample -> (off3 [9,h,w,2], off2 [9,2h,2w,2], off1 [9,4h,4w,2])."""
+    mi = np.ascontiguousarray(max_idx, dtype=np.int64)
+    assert mi.shape == (h - 2, w - 2)
+    outs = [np.empty((9, h * s, w * s, 2), np.float32) for s in (1, 2, 4)]
+    _chk(lib().c2m_oracle_build_pre_offsets(mi, h, w, *[o.ctypes.data_as(ctypes.c_void_p) for o in outs]),
+         "build_pre_offsets")
+    return tuple(outs)
+
+
+def _geom(inp, weight, stride, padding, dilation):
+    b, c, h, w = inp.shape
+    co, _, kh, kw = weight.shape
+    sh, sw = stride
+    ph, pw = padding
+    dh, dw = dilation
+    ho = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    wo = (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    return (b, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw), ho, wo
+
+
+def dcn_v2_forward(inp, weight, bias, offset, mask, stride=(1, 1), padding=(1, 1), dilation=(1, 1), deformable_groups=1):
+    inp, weight, bias, offset, mask = map(_f32, (inp, weight, bias, offset, mask))
+    g, ho, wo = _geom(inp, weight, stride, padding, dilation)
+    out = np.empty((g[0], g[4], ho, wo), np.float32)
+    _chk(lib().c2m_oracle_dcn_v2_forward(inp, weight, bias, offset, mask, *g, deformable_groups, out), "dcn_v2_forward")
+    return out
+
+
+def dcn_v2_backward(inp, weight, bias, offset, mask, grad_out, stride=(1, 1), padding=(1, 1), dilation=(1, 1),
+                    deformable_groups=1):
+    inp, weight, bias, offset, mask, grad_out = map(_f32, (inp, weight, bias, offset, mask, grad_out))
+    g, _, _ = _geom(inp, weight, stride, padding, dilation)
+    gi, go, gm, gw, gb = (np.empty_like(a) for a in (inp, offset, mask, weight, bias))
+    _chk(lib().c2m_oracle_dcn_v2_backward(inp, weight, bias, offset, mask, grad_out, *g, deformable_groups,
+                                          gi, go, gm, gw, gb), "dcn_v2_backward")
+    return gi, go, gm, gw, gb
