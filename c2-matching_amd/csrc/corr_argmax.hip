@@ -1,0 +1,477 @@
+// corr_argmax.hip -- LR<->Ref 3x3 patch-feature correlation with running arg-max, for gfx950 (MI355X).
+//
+// Replaces sample_patches + feature_match_index (reference: mmsr/models/archs/ref_map_util.py:4-23, 26-86) and the
+// caller's per-sample Python loop (mmsr/models/archs/corres_generation_arch.py:52-67) with one batched launch.
+//
+// The reference materialises every ref patch as a conv2d filter (9x copy of the ref map) and a [Nr x Nq] score
+// volume per chunk.  Here neither exists.  The patch score is rewritten as a 9-tap diagonal sum of PIXEL-level
+// channel dot products
+//        S[q][n] = sum_{i,j in 0..2} D[q + (i,j)][n + (i,j)],   D[p][r] = sum_c in[c][p] * ref[c][r]
+// which needs 8.6x fewer multiply-adds than the patch-level contraction.  D is produced by fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bit-identical to the C oracle's loop), never leaves the CU:
+//
+//   * one workgroup (8 waves) owns a 16x16 PIXEL tile of the query map = 14x14 query patches; each wave keeps its
+//     32 query pixels x C channels resident in C/2 VGPRs as MFMA A-operands for the whole sweep;
+//   * the ref map is swept in x-tiles of 32 pixels (30 patches) and, inside an x-tile, one PIXEL ROW per step;
+//     the row segment [C][32] is DMA'd global->LDS (double buffered, global_load_lds) and is the B-operand of
+//     all 8 waves;
+//   * each step yields D[256 query pixels][32 ref pixels] -> a 3-slab LDS ring (rows y-2, y-1, y); once row y is
+//     in, the patch row ry = y-2 is complete: lanes (= ref x) add the nine taps, scale by the precomputed inverse
+//     patch norm and update a per-lane running (max, argmin-index); that VALU/LDS work is interleaved with the
+//     next step's MFMA chain;
+//   * after the sweep a 32-lane shuffle reduction with the (larger value, then lower index) rule yields the
+//     reference's "first maximum" semantics exactly, independent of the visiting order.
+//
+// LDS: ring 3*256*32*4 = 96 KiB + row buffers 2*C*32*4 = 64 KiB (C=256) = all 160 KiB of a CU; 1 workgroup per CU,
+// 2 waves per SIMD.  Roofline: MFMA (fp32 matrix peak 157.3 TF); HBM traffic is ~the compulsory 53 MB/pair.
+#include "c2m_common.h"
+
+namespace c2m {
+
+// ------------------------------------------------------------------------------------------------------------------
+// small prologue kernels
+// ------------------------------------------------------------------------------------------------------------------
+
+// F.normalize over channels (corres_generation_arch.py:56-58): thread = pixel, coalesced over pixels per channel.
+__global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __restrict__ x, int C, int HW,
+                                                                 float* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float* xb = x + (size_t)blockIdx.y * C * HW + p;
+  float* ob = out + (size_t)blockIdx.y * C * HW + p;
+  float ss = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const float v = xb[(size_t)c * HW];
+    ss = fmaf(v, v, ss);
+  }
+  const float nrm = sqrtf(ss);
+  const float den = nrm > 1e-12f ? nrm : 1e-12f;
+  for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = xb[(size_t)c * HW] / den;
+}
+
+// per-pixel sum of squares over channels (canonical fmaf chain, c ascending)
+__global__ void __launch_bounds__(256) pixel_sumsq_kernel(const float* __restrict__ x, int C, int HW,
+                                                           float* __restrict__ ss) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float* xb = x + (size_t)blockIdx.y * C * HW + p;
+  float a = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const float v = xb[(size_t)c * HW];
+    a = fmaf(v, v, a);
+  }
+  ss[(size_t)blockIdx.y * HW + p] = a;
+}
+
+// patch norm over (C,P,P) from the pixel sums (ref_map_util.py:63 / :80): row-major plain adds, sqrt, + 1e-5.
+// invert != 0 -> 1/(norm + 1e-5) (the factor applied to ref patches); else norm + 1e-5 (the query-side divisor).
+__global__ void __launch_bounds__(256) patch_norm_kernel(const float* __restrict__ ss, int H, int W, int P,
+                                                          int stride, int Hp, int Wp, int invert,
+                                                          float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= Hp * Wp) return;
+  const int py = n / Wp, px = n - py * Wp;
+  const float* s = ss + (size_t)blockIdx.y * H * W + (size_t)(py * stride) * W + px * stride;
+  float a = s[0];
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) {
+      if (i == 0 && j == 0) continue;
+      a = a + s[i * W + j];
+    }
+  const float d = sqrtf(a) + 1e-5f;
+  out[(size_t)blockIdx.y * Hp * Wp + n] = invert ? 1.0f / d : d;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// generic kernel: any patch size / strides / channel count.  One workgroup per query patch; the query patch's
+// P*P*C values sit in LDS, threads stride over ref patches (coalesced over rx).  Same arithmetic as the MFMA
+// kernel and the oracle -> bit-identical results.  Used for configurations the fast kernel does not cover and
+// as an on-device cross-check.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) corr_argmax_generic_kernel(
+    const float* __restrict__ fin, const float* __restrict__ fref, int C, int Hq, int Wq, int Hr, int Wr, int P,
+    int sq, int sr, int Wqp, int Hrp, int Wrp, const float* __restrict__ inv, const float* __restrict__ qden,
+    int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
+  extern __shared__ __attribute__((aligned(16))) float qlds[];  // [P*P][C]
+  __shared__ float red_v[256];
+  __shared__ int red_i[256];
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int qy = q / Wqp, qx = q - qy * Wqp;
+  const int HWq = Hq * Wq, HWr = Hr * Wr, Nrp = Hrp * Wrp, PP = P * P;
+  const float* fi = fin + (size_t)b * C * HWq;
+  const float* fr = fref + (size_t)b * C * HWr;
+  for (int e = threadIdx.x; e < PP * C; e += 256) {
+    const int t = e / C, c = e - t * C;
+    const int i = t / P, j = t - i * P;
+    qlds[e] = fi[(size_t)c * HWq + (qy * sq + i) * Wq + qx * sq + j];
+  }
+  __syncthreads();
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int n = threadIdx.x; n < Nrp; n += 256) {
+    const int ry = n / Wrp, rx = n - ry * Wrp;
+    float s = 0.0f;
+    for (int t = 0; t < PP; ++t) {
+      const int i = t / P, j = t - i * P;
+      const float* r = fr + (ry * sr + i) * Wr + rx * sr + j;
+      const float* ql = qlds + t * C;
+      float d = 0.0f;
+      for (int c = 0; c < C; ++c) d = fmaf(ql[c], r[(size_t)c * HWr], d);
+      s = (t == 0) ? d : s + d;
+    }
+    const float v = inv ? s * inv[(size_t)b * Nrp + n] : s;
+    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+  }
+  red_v[threadIdx.x] = best;
+  red_i[threadIdx.x] = bidx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      const float v2 = red_v[threadIdx.x + off];
+      const int i2 = red_i[threadIdx.x + off];
+      if (v2 > red_v[threadIdx.x] || (v2 == red_v[threadIdx.x] && i2 < red_i[threadIdx.x])) {
+        red_v[threadIdx.x] = v2;
+        red_i[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float v = red_v[0];
+    if (qden) v = v / qden[(size_t)b * gridDim.x + q];
+    max_idx[(size_t)b * gridDim.x + q] = (int64_t)red_i[0];
+    max_val[(size_t)b * gridDim.x + q] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA sliding-window kernel (patch 3, strides 1)
+// ------------------------------------------------------------------------------------------------------------------
+namespace corr {
+constexpr int TQ = 16;            // query tile side, pixels
+constexpr int TPQ = TQ - 2;       // query patches per tile side (14)
+constexpr int NQP = TPQ * TPQ;    // 196 query patches per tile
+constexpr int WT = 32;            // ref x-tile width, pixels (= MFMA N)
+constexpr int WP = WT - 2;        // ref patches per x-tile (30)
+constexpr int NWAVE = 8;
+constexpr int NTHR = NWAVE * 64;
+constexpr int QPIX = TQ * TQ;     // 256 query pixels per tile
+constexpr int SLAB = QPIX * WT;   // floats per ring slab
+constexpr int NIT = (NQP + 15) / 16;  // 13 tap-sum rounds: 16 query patches per round (8 waves x 2 half-waves)
+}  // namespace corr
+
+template <int C>
+__global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
+    const float* __restrict__ fin, const float* __restrict__ fref, int Hq, int Wq, int Hr, int Wr, int tiles_y,
+    int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int64_t* __restrict__ max_idx,
+    float* __restrict__ max_val) {
+  using namespace corr;
+  constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
+  constexpr int KPG = (KP + NIT - 1) / NIT;    // k-pairs issued between two tap-sum rounds
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ring = smem;                          // [3][QPIX][WT]
+  float* rbuf = smem + 3 * SLAB;               // [2][C][WT]
+
+  const int ntile = tiles_y * tiles_x;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);  // sample-major: tiles of one sample share an XCD's L2
+  const int b = vb / ntile, tile = vb - b * ntile;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int qy0 = ty * TPQ, qx0 = tx * TPQ;
+  const int Hqp = Hq - 2, Wqp = Wq - 2, Hrp = Hr - 2, Wrp = Wr - 2;
+  (void)Hrp;
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, hi = l >> 5, j32 = l & 31;
+
+  const float* fi = fin + (size_t)b * C * Hq * Wq;
+  const float* fr = fref + (size_t)b * C * Hr * Wr;
+  const float* invb = inv ? inv + (size_t)b * Hrp * Wrp : nullptr;
+
+  // ---- resident A operands: lane (i = l&31, k = l>>5) of k-pair t holds in[2t + k][tile pixel 32w + i] ----
+  float qreg[KP];
+  {
+    const int py = min(qy0 + 2 * w + (j32 >> 4), Hq - 1);
+    const int px = min(qx0 + (j32 & 15), Wq - 1);
+    const float* src = fi + (size_t)hi * Hq * Wq + (size_t)py * Wq + px;
+#pragma unroll
+    for (int t = 0; t < KP; ++t) qreg[t] = src[(size_t)(2 * t) * Hq * Wq];
+  }
+
+  // ---- tap-sum bookkeeping: round `it` handles query patch p = it*16 + w*2 + hi for lane-column rx = j32 ----
+  float best[NIT];
+  int bidx[NIT];
+  int pbase[NIT];  // float index of D[(qy, qx)][rx] inside a slab
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    best[it] = -INFINITY;
+    bidx[it] = 0x7fffffff;
+    const int p = it * 16 + w * 2 + hi;
+    const int qy = p / TPQ, qx = p - qy * TPQ;
+    pbase[it] = (qy * TQ + qx) * WT + j32;  // p >= NQP (last round only) reads in-bounds garbage, masked below
+  }
+
+  const int nxt = (Wrp + WP - 1) / WP;
+  const int S = nxt * Hr;
+
+  // DMA of ref pixel row (xt, y) into rbuf[buf]: wave w copies channels [32w, 32w+32) as 16 x (2 channels x 32 px)
+  auto issue_row = [&](int xt, int y, int buf) {
+    const int x = min(xt * WP + j32, Wr - 1);
+    const float* g = fr + (size_t)(w * (C / NWAVE) + hi) * Hr * Wr + (size_t)y * Wr + x;
+    float* d = rbuf + buf * (C * WT) + w * (C / NWAVE) * WT;
+#pragma unroll
+    for (int m = 0; m < C / NWAVE / 2; ++m) glds_b32(g + (size_t)(2 * m) * Hr * Wr, d + (2 * m) * WT);
+  };
+
+  issue_row(0, 0, 0);
+
+  // Step s processes ref pixel row y of x-tile xt and parks its D tile in ring slab s % 3.  While its MFMA chain
+  // runs, the lanes finish the patch row completed by step s-1 (rows of steps s-3, s-2, s-1 = slabs s%3, (s+1)%3,
+  // (s+2)%3).  Iteration s == S only drains the last pending patch row (its MFMA result is never read).
+  int y = 0, xt = 0;   // row / x-tile of step s
+  int sl0 = 0;         // s % 3
+  // pending candidate of the NEXT iteration, prefetched one step ahead so its global load never sits between
+  // a row DMA and that DMA's wait
+  bool cand_ok = false;
+  int n = 0;
+  float scale_next = 1.0f;
+  for (int s = 0; s <= S; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (A) row s landed in rbuf[s&1]; slab of step s-1 complete; everybody left step s-1
+    float scale = scale_next;
+    asm volatile("" : "+v"(scale));  // consume the prefetched load before any DMA is in flight
+
+    // next row's DMA into the other buffer (its last readers were the MFMAs of step s-1)
+    int yn = y + 1, xtn = xt;
+    if (yn == Hr) { yn = 0; xtn = xt + 1; }
+    if (s + 1 < S) issue_row(xtn, yn, (s + 1) & 1);
+
+    const int sl1 = (sl0 == 2) ? 0 : sl0 + 1;
+    const int sl2 = (sl1 == 2) ? 0 : sl1 + 1;
+    const float* r0 = ring + sl0 * SLAB;                 // ref row ry     (tap row i = 0)
+    const float* r1 = ring + sl1 * SLAB + TQ * WT;       // ref row ry + 1 (i = 1: query pixel row + 1)
+    const float* r2 = ring + sl2 * SLAB + 2 * TQ * WT;   // ref row ry + 2 (i = 2)
+
+    const float* bsrc = rbuf + (s & 1) * (C * WT) + l;  // B operand of k-pair t: rbuf[2t + hi][j32] = bsrc[t * 64]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+      for (int t = it * KPG; t < (it + 1) * KPG && t < KP; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
+
+      // nine taps, row-major, plain adds (oracle order)
+      const int pb = pbase[it];
+      float sum = r0[pb];
+      sum = sum + r0[pb + WT + 1];
+      sum = sum + r0[pb + 2 * WT + 2];
+      sum = sum + r1[pb];
+      sum = sum + r1[pb + WT + 1];
+      sum = sum + r1[pb + 2 * WT + 2];
+      sum = sum + r2[pb];
+      sum = sum + r2[pb + WT + 1];
+      sum = sum + r2[pb + 2 * WT + 2];
+      const float v = invb ? sum * scale : sum;
+      const bool take = cand_ok && (v > best[it] || (v == best[it] && n < bidx[it]));
+      best[it] = take ? v : best[it];
+      bidx[it] = take ? n : bidx[it];
+    }
+
+    // candidate handled by the NEXT iteration: the patch row completed by THIS step (row y of x-tile xt)
+    {
+      const int ncol = xt * WP + j32;
+      cand_ok = (s < S) && (y >= 2) && (j32 < WP) && (ncol < Wrp);
+      n = (y - 2) * Wrp + ncol;
+      scale_next = 1.0f;
+      if (invb && cand_ok) scale_next = invb[n];
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
+
+    // D tile of this wave -> slab s % 3: rows 32w + i, i = (r&3) + 8*(r>>2) + 4*hi ; column j32
+    {
+      float* dst = ring + sl0 * SLAB + (32 * w + 4 * hi) * WT + j32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * WT] = acc[r];
+    }
+
+    y = yn;
+    xt = xtn;
+    sl0 = sl1;
+  }
+
+  // ---- final reduction over the 32 ref-column lanes of each half-wave, then one store per query patch ----
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float v = best[it];
+    int i = bidx[it];
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) {
+      const float v2 = __shfl_xor(v, m, 64);
+      const int i2 = __shfl_xor(i, m, 64);
+      const bool take = (v2 > v) || (v2 == v && i2 < i);
+      v = take ? v2 : v;
+      i = take ? i2 : i;
+    }
+    const int p = it * 16 + w * 2 + hi;
+    const int qy = p / TPQ, qx = p - qy * TPQ;
+    const int gy = qy0 + qy, gx = qx0 + qx;
+    if (j32 == 0 && p < NQP && gy < Hqp && gx < Wqp) {
+      const size_t o = (size_t)b * Hqp * Wqp + (size_t)gy * Wqp + gx;
+      if (qden) v = v / qden[o];
+      max_idx[o] = (int64_t)i;
+      max_val[o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pre-offset builder: index_to_flow (corres_generation_arch.py:29-46) + tensor_shift x9 at scales 1, 2, 4
+// (:69-104, arch_util.py:291-315).  One thread per output pixel of one (sample, shift); writes (x, y) as float2.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pre_offset_kernel(const int64_t* __restrict__ max_idx, int h, int w, int s,
+                                                          float2* __restrict__ out) {
+  const int H = h * s, W = w * s, hp = h - 2, wp = w - 2;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H * W) return;
+  const int k = blockIdx.y, b = blockIdx.z;
+  const int y = pix / W, x = pix - y * W;
+  const int ys = y - (k / 3) * s, xs = x - (k % 3) * s;
+  float2 f = make_float2(0.0f, 0.0f);
+  if (ys >= 0 && xs >= 0) {
+    const int yy = ys / s, xx = xs / s;
+    if (yy < hp && xx < wp) {
+      const int64_t idx = max_idx[(size_t)b * hp * wp + (size_t)yy * wp + xx];
+      f.x = (float)((int)(idx % wp) - xx) * (float)s;  // flow decoded with the QUERY grid width (:32-34)
+      f.y = (float)((int)(idx / wp) - yy) * (float)s;
+    }
+  }
+  out[((size_t)b * 9 + k) * H * W + pix] = f;
+}
+
+}  // namespace c2m
+
+// ====================================================================================================================
+// C-ABI
+// ====================================================================================================================
+using namespace c2m;
+
+extern "C" int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out) {
+  if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return C2M_ERR_INVALID_ARG;
+  dim3 grid(ceil_div(HW, 256), B);
+  hipLaunchKernelGGL(feature_normalize_kernel, grid, dim3(256), 0, as_stream(stream), x, C, HW, out);
+  return check_launch();
+}
+
+namespace {
+struct CorrWs {
+  size_t ss_ref, inv, ss_in, qden, total;  // byte offsets
+};
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
+  CorrWs w;
+  size_t o = 0;
+  w.ss_ref = o; o = align256(o + sizeof(float) * (size_t)B * Hr * Wr);
+  w.inv = o;    o = align256(o + sizeof(float) * (size_t)B * Hr * Wr);
+  w.ss_in = o;  o = align256(o + sizeof(float) * (size_t)B * Hq * Wq);
+  w.qden = o;   o = align256(o + sizeof(float) * (size_t)B * Hq * Wq);
+  w.total = o;
+  return w;
+}
+
+template <int C>
+int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B, int Hq, int Wq, int Hr, int Wr,
+                     const float* inv, const float* qden, int64_t* max_idx, float* max_val) {
+  using namespace c2m::corr;
+  const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
+  const size_t lds = sizeof(float) * (size_t)(3 * SLAB + 2 * C * WT);
+  static bool attr_set = false;  // idempotent; a race only repeats the call
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_argmax_mfma_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  dim3 grid(B * tiles_y * tiles_x);
+  ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
+  hipLaunchKernelGGL(corr_argmax_mfma_kernel<C>, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y,
+                     tiles_x, inv, qden, max_idx, max_val);
+  return check_launch();
+}
+}  // namespace
+
+extern "C" size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr) {
+  if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0) return 0;
+  return corr_ws(B, Hq, Wq, Hr, Wr).total;
+}
+
+extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* feat_in, const float* feat_ref, int B,
+                                           int C, int Hq, int Wq, int Hr, int Wr, int patch, int in_stride,
+                                           int ref_stride, int is_norm, int norm_input, int force_generic,
+                                           int64_t* max_idx, float* max_val, void* workspace,
+                                           size_t workspace_bytes) {
+  if (!feat_in || !feat_ref || !max_idx || !max_val) return C2M_ERR_INVALID_ARG;
+  if (B <= 0 || C <= 0 || patch <= 0 || in_stride <= 0 || ref_stride <= 0) return C2M_ERR_INVALID_ARG;
+  if (Hq < patch || Wq < patch || Hr < patch || Wr < patch) return C2M_ERR_INVALID_ARG;
+  const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr);
+  if (!workspace || workspace_bytes < ws.total) return C2M_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  char* wsb = static_cast<char*>(workspace);
+  float* ss_ref = reinterpret_cast<float*>(wsb + ws.ss_ref);
+  float* inv = reinterpret_cast<float*>(wsb + ws.inv);
+  float* ss_in = reinterpret_cast<float*>(wsb + ws.ss_in);
+  float* qden = reinterpret_cast<float*>(wsb + ws.qden);
+
+  const int Hqp = (Hq - patch) / in_stride + 1, Wqp = (Wq - patch) / in_stride + 1;
+  const int Hrp = (Hr - patch) / ref_stride + 1, Wrp = (Wr - patch) / ref_stride + 1;
+  int rc;
+  if (is_norm) {
+    hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hr * Wr, 256), B), dim3(256), 0, st, feat_ref, C, Hr * Wr,
+                       ss_ref);
+    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hrp * Wrp, 256), B), dim3(256), 0, st, ss_ref, Hr, Wr, patch,
+                       ref_stride, Hrp, Wrp, 1, inv);
+    if ((rc = check_launch()) != C2M_OK) return rc;
+  }
+  if (norm_input) {
+    hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hq * Wq, 256), B), dim3(256), 0, st, feat_in, C, Hq * Wq,
+                       ss_in);
+    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hqp * Wqp, 256), B), dim3(256), 0, st, ss_in, Hq, Wq, patch,
+                       in_stride, Hqp, Wqp, 0, qden);
+    if ((rc = check_launch()) != C2M_OK) return rc;
+  }
+  const float* invp = is_norm ? inv : nullptr;
+  const float* qdp = norm_input ? qden : nullptr;
+
+  const bool fast = !force_generic && patch == 3 && in_stride == 1 && ref_stride == 1 &&
+                    (C == 64 || C == 128 || C == 256);
+  if (fast) {
+    if (C == 256) return launch_corr_mfma<256>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
+    if (C == 128) return launch_corr_mfma<128>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
+    return launch_corr_mfma<64>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
+  }
+  const size_t lds = sizeof(float) * (size_t)patch * patch * C;
+  if (lds > 60 * 1024) return C2M_ERR_UNSUPPORTED;
+  ProfileScope prof(C2M_KERNEL_CORR_GENERIC, st);
+  hipLaunchKernelGGL(corr_argmax_generic_kernel, dim3(Hqp * Wqp, B), dim3(256), lds, st, feat_in, feat_ref, C, Hq, Wq,
+                     Hr, Wr, patch, in_stride, ref_stride, Wqp, Hrp, Wrp, invp, qdp, max_idx, max_val);
+  return check_launch();
+}
+
+extern "C" int c2m_build_pre_offsets_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int h, int w,
+                                         float* off3, float* off2, float* off1) {
+  if (!max_idx || B <= 0 || h < 3 || w < 3) return C2M_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  float* outs[3] = {off3, off2, off1};
+  const int scales[3] = {1, 2, 4};
+  for (int i = 0; i < 3; ++i) {
+    if (!outs[i]) continue;
+    const int s = scales[i];
+    hipLaunchKernelGGL(pre_offset_kernel, dim3(ceil_div(h * s * w * s, 256), 9, B), dim3(256), 0, st, max_idx, h, w,
+                       s, reinterpret_cast<float2*>(outs[i]));
+  }
+  return check_launch();
+}

@@ -1,0 +1,126 @@
+/*
+ * c2m_hip.h -- C-ABI of libc2m_hip.so: the MI355X (gfx950) implementation of C2-Matching's restoration hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only: no torch / ATen types.  Every pointer is a DEVICE
+ * pointer (HBM) unless stated otherwise; every launch is enqueued on `stream` (a hipStream_t passed as void*) and
+ * returns without synchronising.  Every function returns a c2m_status (0 = ok); nothing prints.
+ *
+ * What each entry point replaces in the reference (paths relative to the upstream checkout):
+ *
+ *   c2m_feature_normalize_f32        F.normalize(feat.reshape(c,-1), dim=0)   mmsr/models/archs/corres_generation_arch.py:56-58
+ *   c2m_feature_match_index_f32      sample_patches + feature_match_index     mmsr/models/archs/ref_map_util.py:4-23, 26-86
+ *                                    (batched: the per-sample Python loop of corres_generation_arch.py:52 becomes grid.y)
+ *   c2m_build_pre_offsets_f32        index_to_flow + 27 tensor_shift copies   mmsr/models/archs/corres_generation_arch.py:29-46, 69-109
+ *                                                                             mmsr/models/archs/arch_util.py:291-315
+ *   c2m_dcn_v2_forward_f32           dcn_v2_cuda_forward + im2col launcher    mmsr/models/archs/DCNv2/src/cuda/dcn_v2_cuda.cu:42-172
+ *                                                                             mmsr/models/archs/DCNv2/src/cuda/dcn_v2_im2col_cuda.h:67-75
+ *   c2m_dcn_v2_backward_f32          dcn_v2_cuda_backward + col2im launchers  mmsr/models/archs/DCNv2/src/cuda/dcn_v2_cuda.cu:206-335
+ *                                                                             mmsr/models/archs/DCNv2/src/cuda/dcn_v2_im2col_cuda.h:77-95
+ *   c2m_dcn_fuse_offsets_f32         chunk/cat/repeat/reorder/add/sigmoid     mmsr/models/archs/DCNv2/dcn_v2.py:229-245
+ *
+ * The reference's FFI for the DCN path is the pybind module `_ext` (DCNv2/src/vision.cpp:3-9).  The Python module
+ * c2-matching_amd/_ext.py exports the same four names with the same argument lists and forwards to this ABI; see
+ * INTEGRATION.md for the ctypes stub a maintainer of the reference would add.
+ */
+#ifndef C2M_HIP_H
+#define C2M_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* c2m_stream_t; /* hipStream_t; NULL = the null stream */
+
+typedef enum c2m_status {
+  C2M_OK = 0,
+  C2M_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, channels % groups != 0, ... */
+  C2M_ERR_UNSUPPORTED = 2,   /* valid request that this build has no kernel for */
+  C2M_ERR_WORKSPACE = 3,     /* workspace pointer null or too small */
+  C2M_ERR_LAUNCH = 4,        /* hipLaunchKernel / hipGetLastError reported a failure */
+  C2M_ERR_NO_DEVICE = 5      /* no gfx950 device visible to the HIP runtime */
+} c2m_status;
+
+int c2m_abi_version(void);                 /* bumped on any signature change; currently 1 */
+const char* c2m_status_string(int status); /* static string, never NULL */
+const char* c2m_last_hip_error(void);      /* hipGetErrorString of the last failing HIP call on this thread */
+int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
+
+/*
+ * Kernel timing for bench.py's roofline line: when enabled, every API call brackets its DOMINANT kernel (the MFMA
+ * correlation sweep, the DCNv2 implicit-GEMM forward, ...) with hipEventRecord on the caller's stream.
+ * c2m_profile_collect synchronises the recorded events, writes the elapsed milliseconds (oldest first) and the
+ * kernel ids (C2M_KERNEL_*) and clears the list.  Off by default; costs two event records per call when on.
+ */
+enum { C2M_KERNEL_CORR_MFMA = 1, C2M_KERNEL_CORR_GENERIC = 2, C2M_KERNEL_DCN_FWD = 3, C2M_KERNEL_DCN_BWD_DATA = 4,
+       C2M_KERNEL_DCN_BWD_WEIGHT = 5 };
+int c2m_profile_enable(int on);
+int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Correlation / index search
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* x, out: [B][C][HW] fp32.  out[b,c,p] = x[b,c,p] / max(||x[b,:,p]||_2, 1e-12).  In-place allowed. */
+int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out);
+
+/* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps). */
+size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr);
+
+/*
+ * feat_in [B][C][Hq][Wq], feat_ref [B][C][Hr][Wr] fp32 contiguous; for every sample b independently
+ *   max_idx[b][qy][qx] = argmax_n corr(q, n),  n = ry * Wrp + rx row-major over the ref patch grid, lowest n on ties
+ *   max_val[b][qy][qx] = that maximum (divided by the query patch norm + 1e-5 when norm_input)
+ * with Hqp = (Hq - patch)/in_stride + 1 etc.  max_idx is int64 (torch.max indices), max_val fp32, both [B][Hqp][Wqp].
+ * patch == 3, both strides == 1 and C in {64,128,256} run the MFMA sliding-window kernel; everything else runs
+ * the generic kernel (same arithmetic, bit-identical results, much slower).  `force_generic` != 0 forces the latter.
+ */
+int c2m_feature_match_index_f32(c2m_stream_t stream, const float* feat_in, const float* feat_ref, int B, int C,
+                                int Hq, int Wq, int Hr, int Wr, int patch, int in_stride, int ref_stride,
+                                int is_norm, int norm_input, int force_generic, int64_t* max_idx, float* max_val,
+                                void* workspace, size_t workspace_bytes);
+
+/*
+ * max_idx [B][h-2][w-2] int64 (h, w = feature-map size of BOTH maps)  ->
+ *   off3 [B][9][h][w][2], off2 [B][9][2h][2w][2], off1 [B][9][4h][4w][2] fp32, last dim (x, y); any may be NULL.
+ */
+int c2m_build_pre_offsets_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int h, int w, float* off3,
+                              float* off2, float* off1);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * DCNv2 (modulated deformable convolution), fp32, NCHW contiguous
+ *   input [B][C][H][W]  weight [Co][C][kh][kw]  bias [Co]
+ *   offset [B][dg*2*kh*kw][Ho][Wo] (channel (g*kh*kw+k)*2 = dy, +1 = dx)   mask [B][dg*kh*kw][Ho][Wo]
+ *   output / grad_output [B][Co][Ho][Wo],  Ho = (H + 2*ph - (dh*(kh-1)+1))/sh + 1
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int dg);
+int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
+                           const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output, void* workspace,
+                           size_t workspace_bytes);
+
+size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
+                                           int pw, int dh, int dw, int dg);
+/* All five gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255). */
+int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
+                            const float* offset, const float* mask, const float* grad_output, int B, int C, int H,
+                            int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                            float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight,
+                            float* grad_bias, void* workspace, size_t workspace_bytes);
+
+/*
+ * conv_out [B][3*dg*K][H][W] (raw output of conv_offset_mask, K = kh*kw), pre_offset [B][K][H][W][2] (x, y) or NULL ->
+ *   offset [B][2*dg*K][H][W] = cat(o1, o2) + interleaved (y, x) pre-offset repeated over the dg groups
+ *   mask   [B][dg*K][H][W]   = sigmoid(third chunk)
+ *   abs_sum (device double, may be NULL): accumulates sum |cat(o1,o2)| for the reference's "offset mean > 100" warning
+ *   without a host sync in the hot path (caller zeroes it).
+ */
+int c2m_dcn_fuse_offsets_f32(c2m_stream_t stream, const float* conv_out, const float* pre_offset, int B, int dg, int K,
+                             int H, int W, float* offset, float* mask, double* abs_sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2M_HIP_H */

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python on deterministic inputs.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference is copied: this script imports
+`mmsr/models/archs/ref_map_util.py` by path and -- with tiny stand-ins for the third-party packages that are not
+installed here (mmcv.scandir, torchvision's VGG layer layout) -- `corres_generation_arch.py`, runs them on CPU and
+stores inputs' seeds + the outputs.  The fixtures are data (arrays), committed next to this script.
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import synth  # noqa: E402
+import c2m_oracle as oracle  # noqa: E402  (only for the deterministic feature normalisation of the INPUTS)
+
+
+def load_ref_map_util():
+    spec = importlib.util.spec_from_file_location("ref_map_util_reference", f"{REF}/mmsr/models/archs/ref_map_util.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def stub_third_party():
+    """Stand-ins for packages the reference imports but the container lacks (mmcv, torchvision, cv2)."""
+    mmcv = types.ModuleType("mmcv")
+    mmcv.scandir = lambda d: sorted(os.listdir(d))
+    runner = types.ModuleType("mmcv.runner")
+    runner.master_only = lambda f: f
+    runner.get_dist_info = lambda: (0, 1)
+    runner.get_time_str = lambda: "t"
+    runner.init_dist = lambda *a, **k: None
+    mmcv.runner = runner
+    sys.modules.update({"mmcv": mmcv, "mmcv.runner": runner, "cv2": types.ModuleType("cv2")})
+    cfg = {"vgg16": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+           "vgg19": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]}
+
+    def ctor(name):
+        def make(pretrained=False):
+            layers, c = [], 3
+            for v in cfg[name]:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(2, 2))
+                else:
+                    layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(inplace=True)]
+                    c = v
+            m = nn.Module()
+            m.features = nn.Sequential(*layers)
+            return m
+        return make
+    tv, tvm, tvv, tvu = (types.ModuleType(n) for n in ("torchvision", "torchvision.models", "torchvision.models.vgg", "torchvision.utils"))
+    tvv.vgg16, tvv.vgg19 = ctor("vgg16"), ctor("vgg19")
+    tv.models, tvm.vgg, tv.utils, tvu.make_grid = tvm, tvv, tvu, None
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.vgg": tvv, "torchvision.utils": tvu})
+    # `_ext` (the reference's CUDA-only pybind module, DCNv2/src/vision.cpp:3-9): the reference has no CPU DCNv2, so
+    # the stand-in forwards to the C oracle.  Golden SR outputs are therefore "reference Python + oracle DCNv2".
+    ext = types.ModuleType("_ext")
+
+    def dcn_v2_forward(inp, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+        o = oracle.dcn_v2_forward(inp.detach().numpy(), weight.detach().numpy(), bias.detach().numpy(),
+                                  offset.detach().numpy(), mask.detach().numpy(), (sh, sw), (ph, pw), (dh, dw), dg)
+        return torch.from_numpy(o)
+
+    def dcn_v2_backward(inp, weight, bias, offset, mask, grad_out, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+        g = oracle.dcn_v2_backward(inp.detach().numpy(), weight.detach().numpy(), bias.detach().numpy(),
+                                   offset.detach().numpy(), mask.detach().numpy(), grad_out.detach().numpy(),
+                                   (sh, sw), (ph, pw), (dh, dw), dg)
+        return [torch.from_numpy(a) for a in g]
+    ext.dcn_v2_forward, ext.dcn_v2_backward = dcn_v2_forward, dcn_v2_backward
+    sys.modules["_ext"] = ext
+
+
+def norm_feat(shape, seed):
+    return oracle.feature_normalize(synth.gaussish(shape, seed))
+
+
+def top2_gap(rmu, fi, fr, patch, s_in, s_ref):
+    """fp64 margin between best and second-best score per query (to classify any future mismatch)."""
+    import torch.nn.functional as F
+    q = F.unfold(torch.from_numpy(fi)[None].double(), patch, stride=s_in)[0]
+    r = F.unfold(torch.from_numpy(fr)[None].double(), patch, stride=s_ref)[0]
+    r = r / (r.norm(dim=0) + 1e-5)
+    t = (r.t() @ q).topk(2, dim=0).values
+    return float((t[0] - t[1]).min())
+
+
+def corr_cases():
+    # name, C, (hq,wq), (hr,wr), patch, in_stride, ref_stride, builder
+    return [
+        ("c256_10v16", 256, (10, 10), (16, 16), 3, 1, 1, None),
+        ("c256_20v20", 256, (20, 20), (20, 20), 3, 1, 1, None),
+        ("c256_40v40", 256, (40, 40), (40, 40), 3, 1, 1, None),
+        ("c64_19v35x33", 64, (19, 23), (35, 33), 3, 1, 1, None),
+        ("c256_21v21_s2", 256, (21, 21), (21, 21), 3, 2, 2, None),
+        ("c32_12v14_p5", 32, (12, 12), (14, 14), 5, 1, 1, None),
+        ("tie_halfcopy", 256, (12, 12), (12, 20), 3, 1, 1, "halfcopy"),
+        ("tie_const", 256, (12, 12), (16, 16), 3, 1, 1, "const"),
+        ("tie_zero", 64, (8, 8), (9, 9), 3, 1, 1, "zero"),
+    ]
+
+
+def build_inputs(name, C, hq, hr, builder, seed):
+    fi = norm_feat((C,) + hq, seed)
+    fr = norm_feat((C,) + hr, seed + 1)
+    if builder == "halfcopy":      # right half of the ref = copy of the left half -> exact ties, lowest index wins
+        fr[:, :, hr[1] // 2:] = fr[:, :, :hr[1] // 2]
+    elif builder == "const":       # a constant block (like zero-padded test images after a conv stack)
+        fr[:, 6:, :] = fr[:, 6:7, 0:1]
+        fi[:, 7:, :] = fr[:, 6:7, 0:1]   # queries inside the same constant block: many exactly-equal maxima
+    elif builder == "zero":
+        fr[:] = 0.0
+    return np.ascontiguousarray(fi), np.ascontiguousarray(fr)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    rmu = load_ref_map_util()
+    out = {}
+    for k, (name, C, hq, hr, patch, s_in, s_ref, builder) in enumerate(corr_cases()):
+        fi, fr = build_inputs(name, C, hq, hr, builder, 100 + 10 * k)
+        for norm_input in (False, True):
+            idx, val = rmu.feature_match_index(torch.from_numpy(fi), torch.from_numpy(fr), patch_size=patch,
+                                               input_stride=s_in, ref_stride=s_ref, is_norm=True, norm_input=norm_input)
+            out[f"{name}/idx"] = idx.numpy().astype(np.int64)
+            out[f"{name}/val_ni{int(norm_input)}"] = val.numpy().astype(np.float32)
+        idx0, val0 = rmu.feature_match_index(torch.from_numpy(fi), torch.from_numpy(fr), patch_size=patch,
+                                             input_stride=s_in, ref_stride=s_ref, is_norm=False, norm_input=False)
+        out[f"{name}/idx_nonorm"] = idx0.numpy().astype(np.int64)
+        out[f"{name}/val_nonorm"] = val0.numpy().astype(np.float32)
+        out[f"{name}/gap"] = np.float64(top2_gap(rmu, fi, fr, patch, s_in, s_ref))
+        out[f"{name}/meta"] = np.array([C, hq[0], hq[1], hr[0], hr[1], patch, s_in, s_ref, 100 + 10 * k], np.int64)
+        print(name, "gap", out[f"{name}/gap"], "idx range", idx.min().item(), idx.max().item())
+    # keep the smallest case's inputs as a guard on the generator itself
+    fi, fr = build_inputs("c256_10v16", 256, (10, 10), (16, 16), None, 100)
+    out["c256_10v16/feat_in"], out["c256_10v16/feat_ref"] = fi, fr
+    np.savez_compressed(os.path.join(HERE, "corr_golden.npz"), **out)
+
+    # ---- CorrespondenceGenerationArch.forward: normalise -> match -> index_to_flow -> 27 shifts (pre_offset dict)
+    stub_third_party()
+    sys.path.insert(0, REF)
+    from mmsr.models.archs.corres_generation_arch import CorrespondenceGenerationArch  # noqa: E402
+    net = CorrespondenceGenerationArch(patch_size=3, stride=1, vgg_layer_list=["relu1_1", "relu2_1", "relu3_1"], vgg_type="vgg19").eval()
+    B, h, w = 2, 12, 14
+    f1 = synth.gaussish((B, 256, h, w), 900)
+    f2 = synth.gaussish((B, 256, h, w), 901)
+    f2[1, :, :, 9:] = 0.0   # zero-padded region in sample 1: exact ties
+    img = synth.uniform((B, 3, 4 * h, 4 * w), 902, 0.0, 1.0)
+    with torch.no_grad():
+        pre, _ = net({"dense_features1": torch.from_numpy(f1), "dense_features2": torch.from_numpy(f2)}, torch.from_numpy(img))
+    po = {"meta": np.array([B, 256, h, w, 900, 901], np.int64)}
+    for k, v in pre.items():
+        po[k] = v.numpy().astype(np.float32)
+        print(k, v.shape)
+    np.savez_compressed(os.path.join(HERE, "pre_offset_golden.npz"), **po)
+
+
+if __name__ == "__main__":
+    main()

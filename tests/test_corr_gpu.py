@@ -1,0 +1,165 @@
+"""GPU parity tests of the correlation / index-search path.  Everything goes through the C-ABI (ctypes -> libc2m_hip.so).
+
+Bar: index maps AND values bit-identical to the CPU oracle (same canonical fp32 order, see oracle/c2m_oracle.c), index
+maps identical to the golden vectors produced by the reference's own Python."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(dev):
+    import c2m_amd
+    import c2m_oracle as oracle
+    import synth
+    assert "gfx950" in c2m_amd.device_arch(), c2m_amd.device_arch()
+    return c2m_amd.ops, oracle, synth
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_library_is_loaded_in_tree(env):
+    import c2m_amd
+    assert c2m_amd.LIB_PATH.endswith("c2-matching_amd/csrc/libc2m_hip.so")
+    with open("/proc/self/maps") as f:
+        assert "libc2m_hip.so" in f.read()
+
+
+def test_feature_normalize_bit_exact(env, dev):
+    ops, oracle, synth = env
+    x = synth.gaussish((3, 256, 23, 17), 5)
+    x[1, :, 4, 5] = 0.0  # an all-zero pixel exercises the 1e-12 clamp
+    got = ops.feature_normalize(_t(x, dev)).cpu().numpy()
+    want = np.stack([oracle.feature_normalize(x[b]) for b in range(3)])
+    assert np.array_equal(got, want)
+
+
+def _run_case(ops, oracle, dev, fi, fr, patch=3, s_in=1, s_ref=1, is_norm=True, norm_input=True, force_generic=False):
+    idx, val = ops.feature_match_index_batched(_t(fi[None], dev), _t(fr[None], dev), patch, s_in, s_ref, is_norm, norm_input,
+                                               force_generic=force_generic)
+    oi, ov = oracle.feature_match_index(fi, fr, patch, s_in, s_ref, is_norm, norm_input)
+    return idx[0].cpu().numpy(), val[0].cpu().numpy(), oi, ov
+
+
+def test_golden_cases_bit_exact_vs_oracle_and_reference(env, dev, golden_dir):
+    ops, oracle, _ = env
+    from make_golden import build_inputs, corr_cases
+    gold = np.load(f"{golden_dir}/corr_golden.npz")
+    for k, (name, C, hq, hr, patch, s_in, s_ref, builder) in enumerate(corr_cases()):
+        fi, fr = build_inputs(name, C, hq, hr, builder, 100 + 10 * k)
+        for norm_input in (False, True):
+            gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr, patch, s_in, s_ref, True, norm_input)
+            assert gi.dtype == np.int64
+            assert np.array_equal(gi, oi), f"{name}: HIP index map != oracle"
+            assert np.array_equal(gv, ov), f"{name}: HIP max_val != oracle (bitwise)"
+            assert np.array_equal(gi, gold[f"{name}/idx"]), f"{name}: HIP index map != reference golden"
+            np.testing.assert_allclose(gv, gold[f"{name}/val_ni{int(norm_input)}"], rtol=0, atol=2e-6)
+        gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr, patch, s_in, s_ref, False, False)
+        assert np.array_equal(gi, oi) and np.array_equal(gv, ov), f"{name}: is_norm=False path"
+
+
+@pytest.mark.parametrize("C,hq,hr", [(256, (17, 31), (45, 37)), (128, (16, 16), (3, 3)), (64, (3, 3), (33, 70)),
+                                      (256, (30, 16), (16, 32)), (256, (44, 44), (62, 33))])
+def test_fast_kernel_ragged_shapes(env, dev, C, hq, hr):
+    ops, oracle, synth = env
+    fi = oracle.feature_normalize(synth.gaussish((C,) + hq, 41))
+    fr = oracle.feature_normalize(synth.gaussish((C,) + hr, 42))
+    gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr)
+    assert np.array_equal(gi, oi) and np.array_equal(gv, ov)
+    g2, v2, _, _ = _run_case(ops, oracle, dev, fi, fr, force_generic=True)
+    assert np.array_equal(g2, oi) and np.array_equal(v2, ov)
+
+
+def test_batched_samples_are_independent(env, dev):
+    ops, oracle, synth = env
+    B, C, h, w = 5, 256, 20, 24
+    fi = np.stack([oracle.feature_normalize(synth.gaussish((C, h, w), 60 + b)) for b in range(B)])
+    fr = np.stack([oracle.feature_normalize(synth.gaussish((C, h, w), 70 + b)) for b in range(B)])
+    fr[3, :, :, 12:] = fr[3, :, :, :12]  # exact ties in one sample only
+    idx, val = ops.feature_match_index_batched(_t(fi, dev), _t(fr, dev), 3, 1, 1, True, True)
+    for b in range(B):
+        oi, ov = oracle.feature_match_index(fi[b], fr[b], 3, 1, 1, True, True)
+        assert np.array_equal(idx[b].cpu().numpy(), oi) and np.array_equal(val[b].cpu().numpy(), ov)
+
+
+def test_midsize_80(env, dev):
+    ops, oracle, synth = env
+    fi = oracle.feature_normalize(synth.gaussish((256, 80, 80), 81))
+    fr = oracle.feature_normalize(synth.gaussish((256, 80, 80), 82))
+    gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr)
+    assert np.array_equal(gi, oi) and np.array_equal(gv, ov)
+
+
+def test_full_size_160_properties(env, dev):
+    """BASELINE config 2 shape (one pair of the batch): fast == generic kernel bitwise over the whole map, oracle on
+    a slice of query rows, zero-padded ref (500x500 inside 640x640 -> 125x125 inside 160x160 features) ties -> lowest
+    index, and every reported maximum really is the score of the reported index."""
+    ops, oracle, synth = env
+    C, h = 256, 160
+    fi = oracle.feature_normalize(synth.gaussish((C, h, h), 91))
+    raw = synth.gaussish((C, h, h), 92)
+    raw[:, 125:, :] = raw[:, 125:126, 125:126]
+    raw[:, :, 125:] = raw[:, 125:126, 125:126]   # constant "padded" band: thousands of identical ref patches
+    fr = oracle.feature_normalize(raw)
+    fi[:, 150:, 150:] = fr[:, 130:131, 130:131]   # queries that match the constant band exactly
+    ti, tr = _t(fi[None], dev), _t(fr[None], dev)
+    idx, val = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True)
+    gidx, gval = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True, force_generic=True)
+    assert torch.equal(idx, gidx) and torch.equal(val, gval)
+    idx, val = idx[0].cpu().numpy(), val[0].cpu().numpy()
+    rows = (0, 2)
+    oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=rows)
+    assert np.array_equal(idx[rows[0]:rows[1]], oi[rows[0]:rows[1]]) and np.array_equal(val[rows[0]:rows[1]], ov[rows[0]:rows[1]])
+    rows = (155, 158)
+    oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=rows)
+    assert np.array_equal(idx[rows[0]:rows[1]], oi[rows[0]:rows[1]]) and np.array_equal(val[rows[0]:rows[1]], ov[rows[0]:rows[1]])
+    # queries inside the constant block tie on every fully-constant ref patch: first one is (125, 125)
+    assert (idx[152:, 152:] == 125 * 158 + 125).all()
+    assert idx.min() >= 0 and idx.max() < 158 * 158
+
+
+def test_pre_offsets_bit_exact(env, dev, golden_dir):
+    ops, oracle, synth = env
+    g = np.load(f"{golden_dir}/pre_offset_golden.npz")
+    B, C, h, w, s1, s2 = (int(v) for v in g["meta"])
+    f1 = synth.gaussish((B, C, h, w), s1)
+    f2 = synth.gaussish((B, C, h, w), s2)
+    f2[1, :, :, 9:] = 0.0
+    n1, n2 = ops.feature_normalize(_t(f1, dev)), ops.feature_normalize(_t(f2, dev))
+    idx, _ = ops.feature_match_index_batched(n1, n2, 3, 1, 1, True, True)
+    o3, o2, o1 = ops.build_pre_offsets(idx, h, w)
+    assert np.array_equal(o3.cpu().numpy(), g["relu3_1"])
+    assert np.array_equal(o2.cpu().numpy(), g["relu2_1"])
+    assert np.array_equal(o1.cpu().numpy(), g["relu1_1"])
+    # subset of scales
+    (only2,) = ops.build_pre_offsets(idx, h, w, scales=(2,))
+    assert torch.equal(only2, o2)
+
+
+def test_errors_are_loud(env, dev):
+    ops, _, _ = env
+    import c2m_amd
+    with pytest.raises(c2m_amd.C2MError):
+        ops.feature_match_index_batched(torch.zeros(1, 4, 8, 8), torch.zeros(1, 4, 8, 8))  # CPU tensors: no fallback
+    with pytest.raises(c2m_amd.C2MError):
+        ops.feature_match_index_batched(torch.zeros(1, 4, 2, 8, device=dev), torch.zeros(1, 4, 8, 8, device=dev))
+    with pytest.raises(c2m_amd.C2MError):
+        ops.feature_normalize(torch.zeros(1, 4, 8, 8, device=dev, dtype=torch.float64))
+
+
+def test_mmsr_ref_map_util_signature(env, dev):
+    ops, oracle, synth = env
+    from mmsr.models.archs.ref_map_util import feature_match_index, sample_patches
+    fi = oracle.feature_normalize(synth.gaussish((256, 12, 13), 3))
+    fr = oracle.feature_normalize(synth.gaussish((256, 14, 11), 4))
+    idx, val = feature_match_index(_t(fi, dev), _t(fr, dev), patch_size=3, input_stride=1, ref_stride=1, is_norm=True, norm_input=True)
+    oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (10, 11)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(val.cpu().numpy(), ov)
+    p = sample_patches(_t(fr, dev), 3, 1)
+    assert tuple(p.shape) == (256, 3, 3, 12 * 9)
+    assert torch.equal(p[:, 1, 2, 9 + 4], _t(fr, dev)[:, 1 + 1, 4 + 2])

@@ -1,0 +1,61 @@
+"""CPU: the C oracle against golden vectors produced by the REFERENCE's own Python (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+import c2m_oracle as oracle
+import synth
+from make_golden import build_inputs, corr_cases
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(f"{golden_dir}/corr_golden.npz")
+
+
+def test_generator_inputs_are_reproducible(gold):
+    fi, fr = build_inputs("c256_10v16", 256, (10, 10), (16, 16), None, 100)
+    assert np.array_equal(fi, gold["c256_10v16/feat_in"])
+    assert np.array_equal(fr, gold["c256_10v16/feat_ref"])
+
+
+@pytest.mark.parametrize("k", range(len(corr_cases())))
+def test_feature_match_index_matches_reference(gold, k):
+    name, C, hq, hr, patch, s_in, s_ref, builder = corr_cases()[k]
+    fi, fr = build_inputs(name, C, hq, hr, builder, 100 + 10 * k)
+    for norm_input in (False, True):
+        idx, val = oracle.feature_match_index(fi, fr, patch, s_in, s_ref, True, norm_input)
+        assert idx.dtype == np.int64 and np.array_equal(idx, gold[f"{name}/idx"]), f"{name}: index map differs"
+        # values: same maths, different fp32 summation order than oneDNN -> tolerance, not bits
+        np.testing.assert_allclose(val, gold[f"{name}/val_ni{int(norm_input)}"], rtol=0, atol=2e-6)
+    idx, val = oracle.feature_match_index(fi, fr, patch, s_in, s_ref, False, False)
+    if gold[f"{name}/gap"] > 0:  # un-normalised scores have their own near-ties only in the exact-tie fixtures
+        assert np.array_equal(idx, gold[f"{name}/idx_nonorm"])
+    np.testing.assert_allclose(val, gold[f"{name}/val_nonorm"], rtol=0, atol=2e-6)
+
+
+def test_tie_rule_is_lowest_index(gold):
+    # right half of the ref is a copy of the left half: every winner must come from the left half
+    idx = gold["tie_halfcopy/idx"]
+    wrp = 20 - 2
+    assert (idx % wrp < 10).all()
+    assert (gold["tie_zero/idx"] == 0).all() and (gold["tie_zero/val_ni0"] == 0).all()
+
+
+def test_qrow_slicing_is_consistent():
+    fi = oracle.feature_normalize(synth.gaussish((64, 14, 11), 7))
+    fr = oracle.feature_normalize(synth.gaussish((64, 9, 13), 8))
+    full = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
+    part = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=(4, 9))
+    assert np.array_equal(full[0][4:9], part[0][4:9]) and np.array_equal(full[1][4:9], part[1][4:9])
+
+
+def test_pre_offsets_match_reference(golden_dir):
+    g = np.load(f"{golden_dir}/pre_offset_golden.npz")
+    B, C, h, w, s1, s2 = (int(v) for v in g["meta"])
+    f1 = synth.gaussish((B, C, h, w), s1)
+    f2 = synth.gaussish((B, C, h, w), s2)
+    f2[1, :, :, 9:] = 0.0
+    for b in range(B):
+        idx, _ = oracle.feature_match_index(oracle.feature_normalize(f1[b]), oracle.feature_normalize(f2[b]), 3, 1, 1, True, True)
+        o3, o2, o1 = oracle.build_pre_offsets(idx, h, w)
+        assert np.array_equal(o3, g["relu3_1"][b]) and np.array_equal(o2, g["relu2_1"][b]) and np.array_equal(o1, g["relu1_1"][b])
