@@ -52,8 +52,8 @@ def corr_step(ops, fin, fref, h):
 
 def corr_executed_flops(B, C, h):
     """MFMA flops the sweep actually issues (tiles incl. halo / quantisation), per launch."""
-    tiles = -(-(h - 2) // 14) ** 2
-    steps = -(-(h - 2) // 30) * h
+    tiles = ((h - 2 + 13) // 14) ** 2
+    steps = ((h - 2 + 29) // 30) * h
     return B * tiles * (steps + 1) * 8 * (C // 2) * (2 * 32 * 32 * 2)
 
 
@@ -75,7 +75,7 @@ def cpu_baseline(h, C, rows=48, threads=None):
     dt = time.perf_counter() - t0
     frac = (rows - 2) / (h - 2)
     # the C oracle (pixel-level restructuring, OpenMP) on the same sample, for context
-    c2m_oracle.set_num_threads(threads)
+    c2m_oracle.set_num_threads(min(threads, 32))
     t0 = time.perf_counter()
     c2m_oracle.feature_match_index(fi.numpy(), fr.numpy(), 3, 1, 1, True, True)
     dt_c = time.perf_counter() - t0
