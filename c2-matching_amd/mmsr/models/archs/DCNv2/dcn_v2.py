@@ -1,0 +1,224 @@
+"""MI355X drop-in for the reference's ``mmsr/models/archs/DCNv2/dcn_v2.py`` (operator signatures of dcn_v2.py:16-253).
+
+Module path, class names, constructor arguments, parameter / sub-module names (= checkpoint keys: ``weight``, ``bias``,
+``conv_offset_mask.{weight,bias}``) and initialisation follow the reference.  The compute goes through ``_ext``
+(this package's C-ABI binding) instead of the reference's CUDA extension.  Differences that are deliberate:
+
+* offset/mask assembly of the ``*_sep*`` modules (chunk, cat, repeat over groups, (x,y)->(y,x) interleave, add,
+  sigmoid -- dcn_v2.py:229-245) is one fused kernel (c2m_dcn_fuse_offsets_f32) instead of ~6 elementwise passes;
+* the "offset mean > 100" warning (dcn_v2.py:247-250) no longer blocks the stream: the mean is reduced on the device and
+  read back asynchronously; the warning is emitted at a later call once the value has arrived.
+"""
+import logging
+import math
+
+import _ext as _backend
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from c2m_amd import ops as _ops
+
+logger = logging.getLogger('base')
+
+
+class _DCNv2(Function):
+    """autograd wrapper with the reference's argument order (dcn_v2.py:16-50)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+        ctx.geom = (_pair(weight.shape[2:4]), _pair(stride), _pair(padding), _pair(dilation), int(deformable_groups))
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
+        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
+        g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(input, weight, bias, offset, mask,
+                                                                 grad_output.contiguous(), kh, kw, sh, sw, ph, pw,
+                                                                 dh, dw, dg)
+        return g_in, g_off, g_mask, g_w, g_b, None, None, None, None
+
+
+dcn_v2_conv = _DCNv2.apply
+
+
+class _FusedOffsets(Function):
+    """conv_offset_mask output (+ pre-offset) -> (offset, mask) in one kernel; backward is two elementwise torch ops."""
+
+    @staticmethod
+    def forward(ctx, conv_out, pre_offset, deformable_groups, taps, abs_sum):
+        offset, mask = _ops.dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, taps, abs_sum)
+        ctx.save_for_backward(mask)
+        return offset, mask
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_offset, g_mask):
+        (mask,) = ctx.saved_tensors
+        return torch.cat((g_offset, g_mask * mask * (1 - mask)), dim=1), None, None, None, None
+
+
+class _OffsetMeanWatch:
+    """Deferred version of the reference's `offset_mean > 100` check: no host sync inside forward."""
+
+    def __init__(self):
+        self._pending = None
+
+    def poll(self):
+        if self._pending is not None:
+            host, event, numel = self._pending
+            if event.query():
+                mean = float(host.item()) / numel
+                if mean > 100:
+                    logger.warning('Offset mean is {}, larger than 100.'.format(mean))
+                self._pending = None
+
+    def push(self, abs_sum, numel):
+        if self._pending is None:
+            host = torch.empty(1, dtype=torch.float64, pin_memory=True)
+            host.copy_(abs_sum, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            self._pending = (host, event, numel)
+
+
+class DCNv2(nn.Module):
+    """Modulated deformable convolution with externally supplied offset and mask (dcn_v2.py:56-95)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super(DCNv2, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.Tensor(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        bound = 1. / math.sqrt(fan_in)
+        self.weight.data.uniform_(-bound, bound)
+        self.bias.data.zero_()
+
+    @property
+    def _taps(self):
+        return self.kernel_size[0] * self.kernel_size[1]
+
+    def _conv(self, x, offset, mask):
+        return dcn_v2_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                           self.deformable_groups)
+
+    def forward(self, input, offset, mask):
+        assert 2 * self.deformable_groups * self._taps == offset.shape[1]
+        assert self.deformable_groups * self._taps == mask.shape[1]
+        return self._conv(input, offset, mask)
+
+
+class _SelfOffsetDCN(DCNv2):
+    """Shared machinery of DCN / DCN_sep / DCN_sep_pre_multi_offset: a `conv_offset_mask` head (zero-initialised,
+    dg*3*kh*kw channels, same kernel/stride/padding as the main conv -- dcn_v2.py:112-124) feeding the fused
+    offset/mask assembly."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super(_SelfOffsetDCN, self).__init__(in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                             deformable_groups)
+        self.conv_offset_mask = nn.Conv2d(self.in_channels, self.deformable_groups * 3 * self._taps,
+                                          kernel_size=self.kernel_size, stride=self.stride, padding=self.padding,
+                                          bias=True)
+        self.init_offset()
+        self._watch = _OffsetMeanWatch()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def _offset_and_mask(self, feat, pre_offset=None, watch=False):
+        raw = self.conv_offset_mask(feat)
+        abs_sum = None
+        if watch:
+            self._watch.poll()
+            abs_sum = torch.zeros(1, dtype=torch.float64, device=raw.device)
+        offset, mask = _FusedOffsets.apply(raw, pre_offset, self.deformable_groups, self._taps, abs_sum)
+        if watch:
+            self._watch.push(abs_sum, offset.numel())
+        return offset, mask
+
+
+class DCN(_SelfOffsetDCN):
+    """Offsets and mask predicted from the input itself (dcn_v2.py:98-133)."""
+
+    def forward(self, input):
+        offset, mask = self._offset_and_mask(input)
+        return self._conv(input, offset, mask)
+
+
+class DCN_sep(_SelfOffsetDCN):
+    '''Use other features to generate offsets and masks (dcn_v2.py:136-184).'''
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1,
+                 extra_offset_mask=True):
+        super(DCN_sep, self).__init__(in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                      deformable_groups)
+        self.extra_offset_mask = extra_offset_mask
+
+    def forward(self, x):
+        feat = x
+        if self.extra_offset_mask:
+            x, feat = x[0], x[1]   # x = [input, features]
+        offset, mask = self._offset_and_mask(feat, watch=True)
+        return self._conv(x, offset, mask)
+
+
+class DCN_sep_pre_multi_offset(_SelfOffsetDCN):
+    '''
+    Use other features to generate offsets and masks.
+
+    Intialized the offset with precomputed non-local offset (dcn_v2.py:187-253).
+    '''
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1,
+                 extra_offset_mask=True):
+        super(DCN_sep_pre_multi_offset, self).__init__(in_channels, out_channels, kernel_size, stride, padding,
+                                                       dilation, deformable_groups)
+        self.extra_offset_mask = extra_offset_mask
+
+    def forward(self, x, pre_offset):
+        '''
+        Args:
+            pre_offset: precomputed_offset. Size: [b, 9, h, w, 2], last dim (x, y)
+        '''
+        feat = x
+        if self.extra_offset_mask:
+            x, feat = x[0], x[1]   # x = [input, features]
+        offset, mask = self._offset_and_mask(feat, pre_offset, watch=True)
+        return self._conv(x, offset, mask)
+
+
+class _NotOnThisPath(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("deformable PS-ROI pooling (dcn_v2.py:256-411) is never instantiated by C2-Matching "
+                                  "and is not part of the MI355X hot path")
+
+
+class DCNv2Pooling(_NotOnThisPath):
+    pass
+
+
+class DCNPooling(_NotOnThisPath):
+    pass
+
+
+def dcn_v2_pooling(*args, **kwargs):
+    raise NotImplementedError("deformable PS-ROI pooling is not part of the MI355X hot path")

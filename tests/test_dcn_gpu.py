@@ -1,0 +1,167 @@
+"""GPU parity tests of the DCNv2 path (forward, backward, offset/mask assembly, Python operator).  All calls go through
+the C-ABI.  DCNv2 is floating point with a different summation order than the oracle (MFMA k-order (g,tap,c) vs the
+reference column order c*9+tap; cuBLAS order is unspecified anyway): tolerances are stated per test and are far inside
+north_star's 1e-3 abs bound on SR pixels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(dev):
+    import c2m_amd
+    import c2m_oracle as oracle
+    import synth
+    return c2m_amd.ops, oracle, synth
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, seed, off_scale=3.0):
+    Ho = (H + 2 * pd[0] - (dl[0] * (kh - 1) + 1)) // st[0] + 1
+    Wo = (W + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
+    K = kh * kw
+    x = synth.gaussish((B, C, H, W), seed)
+    w = synth.gaussish((Co, C, kh, kw), seed + 1) * (1.0 / np.sqrt(C * K))
+    b = synth.gaussish((Co,), seed + 2)
+    off = synth.gaussish((B, 2 * K * dg, Ho, Wo), seed + 3) * off_scale
+    off[:, :, 0, :] += 40.0          # a band of far out-of-range samples
+    off[:, 0::2, -1, :] = np.round(off[:, 0::2, -1, :])   # integer coordinates (zero-weight corners)
+    msk = synth.uniform((B, K * dg, Ho, Wo), seed + 4, 0.0, 1.0)
+    return x, w, b, off, msk
+
+
+SHAPES = [
+    # B, C, H, W, Co, kh, kw, stride, pad, dil, dg
+    (2, 256, 12, 14, 256, 3, 3, (1, 1), (1, 1), (1, 1), 8),   # small DynAgg layer (ref_restoration_arch.py:77-85)
+    (2, 128, 17, 19, 128, 3, 3, (1, 1), (1, 1), (1, 1), 8),   # medium (:101-109)
+    (3, 64, 33, 21, 64, 3, 3, (1, 1), (1, 1), (1, 1), 8),     # large (:124-132), ragged pixel count
+    (1, 8, 10, 13, 5, 3, 2, (2, 1), (1, 2), (1, 2), 2),       # strides / dilation / non-square kernel / Co not % 32
+    (1, 16, 9, 9, 40, 1, 1, (1, 1), (0, 0), (1, 1), 4),       # 1x1 kernel, Co = 40
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_matches_oracle(env, dev, shape):
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 300)
+    got = ops.dcn_v2_forward(_t(x, dev), _t(w, dev), _t(b, dev), _t(off, dev), _t(msk, dev), st, pd, dl, dg).cpu().numpy()
+    want = oracle.dcn_v2_forward(x, w, b, off, msk, st, pd, dl, dg)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
+def test_forward_zero_offset_is_conv2d(env, dev):
+    ops, _, synth = env
+    B, C, H, W, Co, dg = 2, 64, 20, 24, 64, 8
+    x, w, b = _t(synth.gaussish((B, C, H, W), 1), dev), _t(synth.gaussish((Co, C, 3, 3), 2) * 0.05, dev), _t(synth.gaussish((Co,), 3), dev)
+    got = ops.dcn_v2_forward(x, w, b, torch.zeros(B, 18 * dg, H, W, device=dev), torch.ones(B, 9 * dg, H, W, device=dev), 1, 1, 1, dg)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    assert float((got - want).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if (s[1] // s[10]) % 4 == 0])
+def test_backward_matches_oracle(env, dev, shape):
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 400, off_scale=2.0)
+    out_shape = oracle.dcn_v2_forward(x, w, b, off, msk, st, pd, dl, dg).shape
+    go = synth.gaussish(out_shape, 410)
+    got = ops.dcn_v2_backward(_t(x, dev), _t(w, dev), _t(b, dev), _t(off, dev), _t(msk, dev), _t(go, dev), st, pd, dl, dg)
+    want = oracle.dcn_v2_backward(x, w, b, off, msk, go, st, pd, dl, dg)
+    for name, g_, w_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, want):
+        g_ = g_.cpu().numpy()
+        assert g_.shape == w_.shape, name
+        tol = 1e-4 * max(1.0, float(np.abs(w_).max()))
+        assert float(np.abs(g_ - w_).max()) <= tol, f"{name}: max err {np.abs(g_ - w_).max()} > {tol}"
+
+
+def test_backward_is_overwriting_not_accumulating(env, dev):
+    ops, _, synth = env
+    B, C, H, W, Co, dg = 1, 32, 8, 9, 32, 8
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, 3, 3, (1, 1), (1, 1), (1, 1), dg, 500)
+    args = [_t(a, dev) for a in (x, w, b, off, msk)] + [_t(synth.gaussish((B, Co, H, W), 501), dev)]
+    g1 = ops.dcn_v2_backward(*args, 1, 1, 1, dg)
+    g2 = ops.dcn_v2_backward(*args, 1, 1, 1, dg)
+    for a, b_ in zip(g1, g2):
+        assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_fuse_offsets_matches_reference_formula(env, dev):
+    """dcn_v2.py:229-245 written with the reference's own tensor ops."""
+    ops, _, synth = env
+    B, dg, K, H, W = 2, 8, 9, 11, 13
+    raw = _t(synth.gaussish((B, 3 * dg * K, H, W), 600), dev)
+    pre = _t(np.round(synth.gaussish((B, K, H, W, 2), 601) * 5), dev)
+    abs_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    offset, mask = ops.dcn_fuse_offsets(raw, pre, dg, K, abs_sum)
+    o1, o2, m = torch.chunk(raw, 3, dim=1)
+    want_off = torch.cat((o1, o2), dim=1)
+    rep = pre.repeat([1, dg, 1, 1, 1])
+    reorder = torch.zeros_like(want_off)
+    reorder[:, 0::2] = rep[..., 1]
+    reorder[:, 1::2] = rep[..., 0]
+    assert torch.equal(offset, want_off + reorder)
+    assert float((mask - torch.sigmoid(m)).abs().max()) < 1e-6
+    assert abs(float(abs_sum) / want_off.numel() - float(want_off.abs().mean())) < 1e-5
+    off2, mask2 = ops.dcn_fuse_offsets(raw, None, dg, K)
+    assert torch.equal(off2, want_off) and torch.equal(mask2, mask)
+
+
+def test_python_operator_forward_backward(env, dev):
+    """DCN_sep_pre_multi_offset through autograd == fp64 autograd of the independent torch restatement."""
+    ops, oracle, synth = env
+    import torch_port
+    from mmsr.models.archs.DCNv2.dcn_v2 import DCN_sep_pre_multi_offset
+    B, C, H, W, dg = 2, 32, 10, 12, 8
+    layer = DCN_sep_pre_multi_offset(C, C, 3, stride=1, padding=1, dilation=1, deformable_groups=dg, extra_offset_mask=True).to(dev)
+    assert float(layer.conv_offset_mask.weight.abs().max()) == 0.0  # zero-initialised head (dcn_v2.py:218-220)
+    with torch.no_grad():
+        layer.conv_offset_mask.weight.copy_(_t(synth.gaussish(tuple(layer.conv_offset_mask.weight.shape), 700) * 0.05, dev))
+        layer.conv_offset_mask.bias.copy_(_t(synth.gaussish((216,), 701) * 0.1, dev))
+    x = _t(synth.gaussish((B, C, H, W), 702), dev).requires_grad_()
+    feat = _t(synth.gaussish((B, C, H, W), 703), dev).requires_grad_()
+    pre = _t(np.round(synth.gaussish((B, 9, H, W, 2), 704) * 3), dev)
+    out = layer([x, feat], pre)
+    go = _t(synth.gaussish(tuple(out.shape), 705), dev)
+    out.backward(go)
+
+    # independent fp64 CPU restatement with stock torch ops
+    xd, fd = x.detach().cpu().double().requires_grad_(), feat.detach().cpu().double().requires_grad_()
+    wd, bd = layer.weight.detach().cpu().double().requires_grad_(), layer.bias.detach().cpu().double().requires_grad_()
+    cw, cb = layer.conv_offset_mask.weight.detach().cpu().double().requires_grad_(), layer.conv_offset_mask.bias.detach().cpu().double().requires_grad_()
+    raw = F.conv2d(fd, cw, cb, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, dim=1)
+    off = torch.cat((o1, o2), dim=1)
+    rep = pre.cpu().double().repeat([1, dg, 1, 1, 1])
+    reorder = torch.zeros_like(off)
+    reorder[:, 0::2] = rep[..., 1]
+    reorder[:, 1::2] = rep[..., 0]
+    ref = torch_port.dcn_v2_reference(xd, wd, bd, off + reorder, torch.sigmoid(m), dg=dg)
+    ref.backward(go.cpu().double())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 1e-4
+    for name, got, want in (("x", x.grad, xd.grad), ("feat", feat.grad, fd.grad), ("weight", layer.weight.grad, wd.grad),
+                            ("bias", layer.bias.grad, bd.grad), ("com.weight", layer.conv_offset_mask.weight.grad, cw.grad),
+                            ("com.bias", layer.conv_offset_mask.bias.grad, cb.grad)):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-4 * max(1.0, float(want.abs().max())), f"{name}: {err}"
+
+
+def test_ext_module_contract(env, dev):
+    import _ext
+    x = torch.zeros(1, 4, 5, 5, device=dev)
+    w = torch.zeros(2, 4, 3, 3, device=dev)
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x.cpu(), w.cpu(), torch.zeros(2), torch.zeros(1, 18, 5, 5), torch.zeros(1, 9, 5, 5), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):  # kernel size mismatch (dcn_v2_cuda.cu:79-80)
+        _ext.dcn_v2_forward(x, w, torch.zeros(2, device=dev), torch.zeros(1, 18, 5, 5, device=dev), torch.zeros(1, 9, 5, 5, device=dev), 5, 5, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        _ext.dcn_v2_psroi_pooling_forward()
+    out = _ext.dcn_v2_forward(x, w, torch.ones(2, device=dev), torch.zeros(1, 18, 5, 5, device=dev), torch.ones(1, 9, 5, 5, device=dev), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    assert tuple(out.shape) == (1, 2, 5, 5) and float((out - 1).abs().max()) == 0.0
