@@ -1,0 +1,30 @@
+"""``ContrasExtractorSep`` (contras_extractor_arch.py:8-59): two VGG16 towers cut after conv3_1 (no ReLU -> signed
+features), one for the bicubic-upsampled LR image and one for the Ref image; producer of the correlation inputs."""
+import torch
+import torch.nn as nn
+
+from mmsr.models.archs.vgg_arch import NAMES, build_vgg_features
+
+
+class ContrasExtractorLayer(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.model = nn.Sequential(build_vgg_features('vgg16', NAMES['vgg16'].index('conv3_1')))
+        self.register_buffer('mean', torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def forward(self, batch):
+        return self.model((batch - self.mean) / self.std)
+
+
+class ContrasExtractorSep(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.feature_extraction_image1 = ContrasExtractorLayer()
+        self.feature_extraction_image2 = ContrasExtractorLayer()
+
+    def forward(self, image1, image2):
+        return {'dense_features1': self.feature_extraction_image1(image1),
+                'dense_features2': self.feature_extraction_image2(image2)}

@@ -1,0 +1,55 @@
+"""MI355X drop-in for ``CorrespondenceGenerationArch`` (corres_generation_arch.py:14-117).
+
+Same constructor kwargs (YAML ``network_map`` block) and the same ``forward(dense_features, img_ref_hr) ->
+(pre_offset, img_ref_feat)`` contract.  What changes underneath:
+
+* the per-sample Python loop (:52) is gone: channel normalisation (:56-58), 3x3 patch matching (:60-67) and the
+  index->flow->27 shifted/upsampled offset maps (:69-104) are three batched kernel launches;
+* the index map never leaves the GPU and no intermediate flow / shifted tensors are allocated.
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from c2m_amd import ops as _ops
+from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
+
+logger = logging.getLogger('base')
+
+
+class CorrespondenceGenerationArch(nn.Module):
+
+    def __init__(self, patch_size=3, stride=1, vgg_layer_list=['relu3_1', 'relu2_1', 'relu1_1'], vgg_type='vgg19'):
+        super(CorrespondenceGenerationArch, self).__init__()
+        self.patch_size = patch_size
+        self.stride = stride
+        self.vgg_layer_list = vgg_layer_list
+        self.vgg = VGGFeatureExtractor(layer_name_list=vgg_layer_list, vgg_type=vgg_type)
+
+    def index_to_flow(self, max_idx):
+        """(h, w) int64 index map of ONE sample -> [1, h+2, w+2, 2] flow (x, y), zero-padded bottom/right
+        (corres_generation_arch.py:29-46).  API compatibility; forward() uses the batched kernel."""
+        h, w = max_idx.shape
+        (flow,) = _ops.build_pre_offsets(max_idx[None].contiguous(), h + 2, w + 2, scales=(1,))
+        return flow[:, 0]
+
+    @torch.no_grad()
+    def match(self, dense_features):
+        """-> (max_idx int64 [B, h-2, w-2], max_val float32 [B, h-2, w-2]) for the whole batch."""
+        feat_in = _ops.feature_normalize(dense_features['dense_features1'])
+        feat_ref = _ops.feature_normalize(dense_features['dense_features2'])
+        return _ops.feature_match_index_batched(feat_in, feat_ref, self.patch_size, self.stride, self.stride,
+                                                is_norm=True, norm_input=True)
+
+    def forward(self, dense_features, img_ref_hr):
+        if self.patch_size != 3 or self.stride != 1:
+            # the 9-shift construction of the reference (:69-104) is tied to 3x3 patches at stride 1
+            raise NotImplementedError('pre-offset generation is defined for patch_size=3, stride=1')
+        h, w = dense_features['dense_features1'].shape[2:]
+        max_idx, _ = self.match(dense_features)
+        off3, off2, off1 = _ops.build_pre_offsets(max_idx, h, w)
+        # size: [b, 9, h, w, 2], the order of the last dim: [x, y]
+        pre_offset = {'relu1_1': off1, 'relu2_1': off2, 'relu3_1': off3}
+        img_ref_feat = self.vgg(img_ref_hr)
+        return pre_offset, img_ref_feat

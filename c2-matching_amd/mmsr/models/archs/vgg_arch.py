@@ -1,0 +1,95 @@
+"""VGG feature taps with the reference's module/parameter naming (``vgg_arch.py:59-145``): ``vgg_net.conv1_1`` ...,
+buffers ``mean`` / ``std``.  torchvision is optional: when it is importable the ImageNet weights are loaded exactly as
+the reference does (``vgg_arch.py:104-105``); offline (no torchvision, no checkpoint download) the same layer stack is
+built locally with random weights -- benchmarks and parity tests overwrite them with seeded values anyway."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+_CFG = {
+    'vgg11': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'vgg13': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'vgg16': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
+    'vgg19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M'],
+}
+
+
+def layer_names(vgg_type):
+    """conv{b}_{i}, relu{b}_{i}, pool{b} in torchvision's `features` order (NAMES table, vgg_arch.py:7-40)."""
+    names, block, idx = [], 1, 1
+    for v in _CFG[vgg_type]:
+        if v == 'M':
+            names.append(f'pool{block}')
+            block, idx = block + 1, 1
+        else:
+            names += [f'conv{block}_{idx}', f'relu{block}_{idx}']
+            idx += 1
+    return names
+
+
+NAMES = {k: layer_names(k) for k in _CFG}
+
+
+def build_vgg_features(vgg_type, upto, pretrained=True):
+    """OrderedDict name -> layer for layers [0, upto] of torchvision's vgg `features` stack."""
+    names = NAMES[vgg_type][:upto + 1]
+    tv_layers = None
+    if pretrained:
+        try:
+            import torchvision.models.vgg as tv_vgg
+            tv_layers = list(getattr(tv_vgg, vgg_type)(pretrained=True).features[:upto + 1])
+        except Exception:  # no torchvision / no network: local stack, caller loads weights from a checkpoint
+            tv_layers = None
+    out, c_in, pos = OrderedDict(), 3, 0
+    for v in _CFG[vgg_type]:
+        n_here = 1 if v == 'M' else 2
+        if pos >= len(names):
+            break
+        if v == 'M':
+            out[names[pos]] = tv_layers[pos] if tv_layers else nn.MaxPool2d(kernel_size=2, stride=2)
+        else:
+            out[names[pos]] = tv_layers[pos] if tv_layers else nn.Conv2d(c_in, v, kernel_size=3, padding=1)
+            if pos + 1 < len(names):
+                out[names[pos + 1]] = tv_layers[pos + 1] if tv_layers else nn.ReLU(inplace=True)
+            c_in = v
+        pos += n_here
+    return out
+
+
+class VGGFeatureExtractor(nn.Module):
+    """Returns {layer_name: feature} for the requested taps (vgg_arch.py:59-145)."""
+
+    def __init__(self, layer_name_list, vgg_type='vgg19', use_input_norm=True, requires_grad=False,
+                 remove_pooling=False, pooling_stride=2):
+        super().__init__()
+        if 'bn' in vgg_type:
+            raise NotImplementedError('batch-norm VGG variants are not used by C2-Matching')
+        self.layer_name_list = layer_name_list
+        self.use_input_norm = use_input_norm
+        self.names = NAMES[vgg_type]
+        last = max(self.names.index(n) for n in layer_name_list)
+        stack = OrderedDict()
+        for name, layer in build_vgg_features(vgg_type, last).items():
+            if 'pool' in name:
+                if remove_pooling:
+                    continue
+                layer = nn.MaxPool2d(kernel_size=2, stride=pooling_stride)
+            stack[name] = layer
+        self.vgg_net = nn.Sequential(stack)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+        if use_input_norm:  # statistics for images in [0, 1]
+            self.register_buffer('mean', torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+            self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def forward(self, x):
+        if self.use_input_norm:
+            x = (x - self.mean) / self.std
+        taps = {}
+        for name, layer in self.vgg_net._modules.items():
+            x = layer(x)
+            if name in self.layer_name_list:
+                taps[name] = x.clone()  # the next ReLU is in-place
+        return taps

@@ -1,0 +1,87 @@
+"""Stage-3 (MSE yaml) slice of the reference's ``RefRestorationModel`` (ref_restoration_model.py:21-43, 47-87,
+186-279): net construction through the registry, the four Adam parameter groups, ``feed_data`` / ``optimize_parameters``
+with the pixel loss / ``test``.  GAN, perceptual, texture losses, validation image I/O and LR schedulers are outside the
+hot path and are not provided here -- ``mmsr/train.py`` of the reference keeps using its own
+model file; this class is what bench/tests drive.
+"""
+import copy
+import logging
+
+import torch
+
+import mmsr.models.networks as networks
+from mmsr.models.base_model import BaseModel, unwrap
+
+logger = logging.getLogger('base')
+
+
+class RefRestorationModel(BaseModel):
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        opt = copy.deepcopy(opt)  # the factories pop 'type'
+        self.net_g = self.model_to_device(networks.define_net_g(opt))
+        # net_map has no trainable parameters; net_extractor's never receive gradients in stage 3: both stay bare
+        self.net_map = self.model_to_device(networks.define_net_map(opt), receives_gradients=False)
+        self.net_extractor = self.model_to_device(networks.define_net_extractor(opt), receives_gradients=False)
+        for p in self.net_extractor.parameters():
+            p.requires_grad = False
+        path = self.opt.get('path') or {}
+        if path.get('pretrain_model_feature_extractor'):
+            self.load_network(self.net_extractor, path['pretrain_model_feature_extractor'], path.get('strict_load', True))
+        if path.get('pretrain_model_g'):
+            self.load_network(self.net_g, path['pretrain_model_g'], path.get('strict_load', True))
+        if self.is_train:
+            self.net_g.train()
+            self._build_optimizer()
+            self.cri_pix = torch.nn.L1Loss()  # pixel_criterion: L1Loss, pixel_weight 1.0 (stage3_restoration_mse.yml:84-85)
+            self.pixel_weight = float(self.opt['train'].get('pixel_weight', 1.0))
+
+    def _build_optimizer(self):
+        """Adam with the reference's four groups keyed on parameter names (ref_restoration_model.py:47-87)."""
+        t = self.opt['train']
+        groups = {'g': [], 'offset': [], 'relu3_offset': [], 'relu2_offset': []}
+        for name, p in unwrap(self.net_g).named_parameters():
+            if not p.requires_grad:
+                continue
+            if 'offset' in name:
+                key = 'relu3_offset' if 'small' in name else 'relu2_offset' if 'medium' in name else 'offset'
+            else:
+                key = 'g'
+            groups[key].append(p)
+        self.optimizer_g = torch.optim.Adam(
+            [{'params': groups['g']},
+             {'params': groups['offset'], 'lr': t['lr_offset']},
+             {'params': groups['relu3_offset'], 'lr': t['lr_relu3_offset']},
+             {'params': groups['relu2_offset'], 'lr': t['lr_relu2_offset']}],
+            lr=t['lr_g'], weight_decay=t.get('weight_decay_g', 0), betas=tuple(t['beta_g']))
+        self.optimizers.append(self.optimizer_g)
+
+    def feed_data(self, data):
+        self.img_in_lq = data['img_in_lq'].to(self.device)
+        self.img_ref = data['img_ref'].to(self.device)
+        self.gt = data['img_in'].to(self.device)
+        self.match_img_in = data['img_in_up'].to(self.device)
+
+    def _correspondence(self):
+        with torch.no_grad():  # non-differentiable past the arg-max; keeps DDP's reducer to net_g only
+            self.features = self.net_extractor(self.match_img_in, self.img_ref)
+            self.pre_offset, self.img_ref_feat = self.net_map(self.features, self.img_ref)
+
+    def optimize_parameters(self, step):
+        self._correspondence()
+        self.output = self.net_g(self.img_in_lq, self.pre_offset, self.img_ref_feat)
+        self.optimizer_g.zero_grad()
+        l_pix = self.cri_pix(self.output, self.gt) * self.pixel_weight
+        l_pix.backward()  # DCNv2 backward x3; DDP all-reduces net_g's gradients (RCCL) while it runs
+        self.optimizer_g.step()
+        self.log_dict['l_g_pix'] = l_pix.detach()  # no .item(): the reference's per-step host sync is dropped
+
+    def test(self):
+        self.net_g.eval()
+        with torch.no_grad():
+            self._correspondence()
+            self.output = self.net_g(self.img_in_lq, self.pre_offset, self.img_ref_feat)
+        if self.is_train:
+            self.net_g.train()
+        return self.output

@@ -124,6 +124,33 @@ def build_inputs(name, C, hq, hr, builder, seed):
     return np.ascontiguousarray(fi), np.ascontiguousarray(fr)
 
 
+def fill_parameters(module, prefix):
+    """Deterministic, name-keyed parameter values (shared with the tests): conv weights ~0.02*g, offset heads 0.01*g
+    (non-zero so the learned offsets are live, unlike the zero-initialised reference state), biases 0.01*g."""
+    sd = module.state_dict()
+    for name, t in sd.items():
+        if name.endswith(("mean", "std")):
+            continue
+        g = synth.gaussish(tuple(t.shape), synth.name_seed(prefix + name))
+        scale = 0.01 if ("conv_offset_mask" in name or name.endswith("bias")) else 0.02
+        sd[name] = torch.from_numpy((g * scale).astype(np.float32))
+    module.load_state_dict(sd)
+
+
+def restoration_inputs(B, h, w):
+    """LR image, pre-offset dict and ref-feature dict for RestorationNet at LR size h x w."""
+    lr = synth.uniform((B, 3, h, w), 1000, 0.0, 1.0)
+    hp, wp = h - 2, w - 2
+    idx = (synth.uniform((B, hp, wp), 1001, 0.0, 1.0).astype(np.float64) * (hp * wp)).astype(np.int64) % (hp * wp)
+    offs = [oracle.build_pre_offsets(idx[b], h, w) for b in range(B)]
+    pre = {"relu3_1": np.stack([o[0] for o in offs]), "relu2_1": np.stack([o[1] for o in offs]),
+           "relu1_1": np.stack([o[2] for o in offs])}
+    feats = {"relu3_1": np.maximum(synth.gaussish((B, 256, h, w), 1002), 0),
+             "relu2_1": np.maximum(synth.gaussish((B, 128, 2 * h, 2 * w), 1003), 0),
+             "relu1_1": np.maximum(synth.gaussish((B, 64, 4 * h, 4 * w), 1004), 0)}
+    return lr, pre, feats
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -165,6 +192,30 @@ def main():
         po[k] = v.numpy().astype(np.float32)
         print(k, v.shape)
     np.savez_compressed(os.path.join(HERE, "pre_offset_golden.npz"), **po)
+
+    # ---- RestorationNet.forward (ref_restoration_arch.py:51-65) at BASELINE config-1 size: LR 40x40 -> SR 160x160.
+    # Inputs are synthetic at the net's interface (LR image, integer-valued pre-offsets from a hashed index map, ref
+    # features) so that the fixture does not depend on how a VGG conv rounds on a particular CPU.
+    from mmsr.models.archs.ref_restoration_arch import RestorationNet  # noqa: E402
+    net_g = RestorationNet(ngf=64, n_blocks=16, groups=8).eval()
+    fill_parameters(net_g, "net_g.")
+    lr, pre, feats = restoration_inputs(1, 40, 40)
+    import json
+    from mmsr.models.archs.contras_extractor_arch import ContrasExtractorSep  # noqa: E402
+    keys = {"net_g": {k: list(v.shape) for k, v in net_g.state_dict().items()},
+            "net_map": {k: list(v.shape) for k, v in net.state_dict().items()},
+            "net_extractor": {k: list(v.shape) for k, v in ContrasExtractorSep().state_dict().items()}}
+    json.dump(keys, open(os.path.join(HERE, "state_dict_keys.json"), "w"), indent=0)
+    taps = {}
+    for stage in ("small", "medium", "large"):  # outputs of the three DynAgg (DCNv2) sites, spatially subsampled
+        getattr(net_g.dyn_agg_restore, f"{stage}_dyn_agg").register_forward_hook(
+            lambda m, i, o, stage=stage: taps.__setitem__(stage, o.detach().numpy()[..., ::5, ::5].copy()))
+    with torch.no_grad():
+        sr = net_g(torch.from_numpy(lr), {k: torch.from_numpy(v) for k, v in pre.items()},
+                   {k: torch.from_numpy(v) for k, v in feats.items()})
+    print("sr", sr.shape, float(sr.abs().mean()), float(sr.std()), {k: float(np.abs(v).mean()) for k, v in taps.items()})
+    np.savez_compressed(os.path.join(HERE, "restoration_golden.npz"), sr=sr.numpy().astype(np.float32),
+                        meta=np.array([1, 40, 40], np.int64), **{f"dyn_agg_{k}": v.astype(np.float32) for k, v in taps.items()})
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ def _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, seed, off_scale=3.0):
     Wo = (W + 2 * pd[1] - (dl[1] * (kw - 1) + 1)) // st[1] + 1
     K = kh * kw
     x = synth.gaussish((B, C, H, W), seed)
-    w = synth.gaussish((Co, C, kh, kw), seed + 1) * (1.0 / np.sqrt(C * K))
+    w = (synth.gaussish((Co, C, kh, kw), seed + 1) * (1.0 / np.sqrt(C * K))).astype(np.float32)
     b = synth.gaussish((Co,), seed + 2)
     off = synth.gaussish((B, 2 * K * dg, Ho, Wo), seed + 3) * off_scale
     off[:, :, 0, :] += 40.0          # a band of far out-of-range samples

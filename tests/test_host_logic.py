@@ -1,0 +1,132 @@
+"""CPU: host-side logic -- registries, checkpoint key layout (drop-in contract), the data-parallel
+wrapper on a world_size-2 gloo group."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arch_registry_builds_the_yaml_blocks():
+    import mmsr.models.networks as networks
+    opt = {"network_g": {"type": "RestorationNet", "ngf": 64, "n_blocks": 2, "groups": 8},
+           "network_map": {"type": "CorrespondenceGenerationArch", "patch_size": 3, "stride": 1,
+                           "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
+           "network_extractor": {"type": "ContrasExtractorSep"}}
+    g, m, e = networks.define_net_g(opt), networks.define_net_map(opt), networks.define_net_extractor(opt)
+    assert type(g).__name__ == "RestorationNet" and type(m).__name__ == "CorrespondenceGenerationArch"
+    assert type(e).__name__ == "ContrasExtractorSep"
+    with pytest.raises(ValueError):
+        networks.dynamical_instantiation(networks._arch_modules, "NoSuchArch", {})
+
+
+def test_state_dict_layout_matches_the_reference(golden_dir):
+    want = json.load(open(f"{golden_dir}/state_dict_keys.json"))
+    from mmsr.models.archs.contras_extractor_arch import ContrasExtractorSep
+    from mmsr.models.archs.corres_generation_arch import CorrespondenceGenerationArch
+    from mmsr.models.archs.ref_restoration_arch import RestorationNet
+    nets = {"net_g": RestorationNet(64, 16, 8),
+            "net_map": CorrespondenceGenerationArch(3, 1, ["relu1_1", "relu2_1", "relu3_1"], "vgg19"),
+            "net_extractor": ContrasExtractorSep()}
+    for name, net in nets.items():
+        got = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert list(got.keys()) == list(want[name].keys()), name
+        assert got == want[name], name
+    assert sum(p.numel() for p in nets["net_g"].parameters()) == 8865547
+    # re_init_dcn_offset state (ref_restoration_arch.py:42-49)
+    for stage in ("small", "medium", "large"):
+        head = getattr(nets["net_g"].dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask
+        assert float(head.weight.abs().max()) == 0.0 and float(head.bias.abs().max()) == 0.0
+    assert not any(p.requires_grad for p in nets["net_map"].parameters())
+
+
+def test_tensor_shift_and_sample_patches_semantics():
+    from mmsr.models.archs.arch_util import tensor_shift
+    from mmsr.models.archs.ref_map_util import sample_patches
+    x = torch.arange(2 * 4 * 5 * 2, dtype=torch.float32).view(2, 4, 5, 2)
+    y = tensor_shift(x, (1, 2))
+    assert torch.equal(y[:, 1:, 2:], x[:, :3, :3]) and float(y[:, 0].abs().max()) == 0 and float(y[:, :, :2].abs().max()) == 0
+    f = torch.randn(3, 6, 7)
+    p = sample_patches(f, 3, 1)
+    assert tuple(p.shape) == (3, 3, 3, 4 * 5)
+    want = f.unfold(1, 3, 1).unfold(2, 3, 1).reshape(3, -1, 3, 3).permute(0, 2, 3, 1)
+    assert torch.equal(p, want)
+    p2 = sample_patches(f, 3, 2)
+    assert torch.equal(p2, f.unfold(1, 3, 2).unfold(2, 3, 2).reshape(3, -1, 3, 3).permute(0, 2, 3, 1))
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(REPO, "c2-matching_amd"))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from mmsr.models.base_model import BaseModel, unwrap
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = BaseModel({"dist": True, "gpu_ids": None, "is_train": True})
+        torch.manual_seed(0)
+        net = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 3, 3, padding=1))
+        frozen = nn.Conv2d(3, 3, 1)
+        for p in frozen.parameters():
+            p.requires_grad = False
+        wrapped = model.model_to_device(net)
+        assert isinstance(wrapped, DistributedDataParallel)
+        assert not isinstance(model.model_to_device(frozen), DistributedDataParallel)       # frozen net stays bare
+        assert not isinstance(model.model_to_device(nn.Conv2d(3, 3, 1), receives_gradients=False), DistributedDataParallel)
+        g = torch.Generator().manual_seed(123)
+        data = torch.randn(4, 3, 8, 8, generator=g)
+        target = torch.randn(4, 3, 8, 8, generator=g)
+        shard = slice(rank * 2, rank * 2 + 2)                                             # batch sharded by rank
+        loss = nn.functional.l1_loss(wrapped(data[shard]), target[shard])
+        loss.backward()
+        grads = [p.grad.clone() for p in unwrap(wrapped).parameters()]
+        q.put((rank, [g_.numpy() for g_ in grads]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_wrapper_gloo_world2_matches_single_process():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process gradient on the concatenated batch
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 3, 3, padding=1))
+    g = torch.Generator().manual_seed(123)
+    data = torch.randn(4, 3, 8, 8, generator=g)
+    target = torch.randn(4, 3, 8, 8, generator=g)
+    nn.functional.l1_loss(net(data), target).backward()
+    for r in range(2):
+        for a, p in zip(got[r], net.parameters()):
+            np.testing.assert_allclose(a, p.grad.numpy(), atol=1e-6)
+
+
+def test_optimizer_groups_follow_parameter_names():
+    from mmsr.models.ref_restoration_model import RefRestorationModel
+    opt = {"dist": False, "gpu_ids": None, "is_train": True, "path": {},
+           "network_g": {"type": "RestorationNet", "ngf": 64, "n_blocks": 1, "groups": 8},
+           "network_map": {"type": "CorrespondenceGenerationArch", "patch_size": 3, "stride": 1,
+                           "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
+           "network_extractor": {"type": "ContrasExtractorSep"},
+           "train": {"lr_g": 1e-4, "lr_offset": 1e-4, "lr_relu2_offset": 1e-5, "lr_relu3_offset": 1e-6,
+                     "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0}}
+    m = RefRestorationModel(opt)
+    lrs = [g["lr"] for g in m.optimizer_g.param_groups]
+    assert lrs == [1e-4, 1e-4, 1e-6, 1e-5]
+    n = [len(g["params"]) for g in m.optimizer_g.param_groups]
+    # 'offset' in name: {small,medium,large}_offset_conv{1,2} and *_dyn_agg.conv_offset_mask, weight+bias each
+    assert n[1] == 6 and n[2] == 6 and n[3] == 6 and sum(n) == len(list(m.net_g.parameters()))
+    assert "network_g" in opt and opt["network_g"]["type"] == "RestorationNet"  # caller's dict untouched
