@@ -259,23 +259,30 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+      // (1) issue the nine tap reads of round `it`; they are consumed only after this round's MFMA group, so their
+      //     LDS latency is covered by ~KPG*64 cycles of matrix work instead of being waited for one by one
+      const int pb = pbase[it];
+      const float t00 = r0[pb], t01 = r0[pb + WT + 1], t02 = r0[pb + 2 * WT + 2];
+      const float t10 = r1[pb], t11 = r1[pb + WT + 1], t12 = r1[pb + 2 * WT + 2];
+      const float t20 = r2[pb], t21 = r2[pb + WT + 1], t22 = r2[pb + 2 * WT + 2];
+      __builtin_amdgcn_sched_barrier(0);
+      // (2) MFMA group: k-pairs [it*KPG, (it+1)*KPG)
 #pragma unroll
       for (int t = it * KPG; t < (it + 1) * KPG && t < KP; ++t)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
-
-      // nine taps, row-major, plain adds (oracle order)
-      const int pb = pbase[it];
-      float sum = r0[pb];
-      sum = sum + r0[pb + WT + 1];
-      sum = sum + r0[pb + 2 * WT + 2];
-      sum = sum + r1[pb];
-      sum = sum + r1[pb + WT + 1];
-      sum = sum + r1[pb + 2 * WT + 2];
-      sum = sum + r2[pb];
-      sum = sum + r2[pb + WT + 1];
-      sum = sum + r2[pb + 2 * WT + 2];
+      __builtin_amdgcn_sched_barrier(0);
+      // (3) nine taps, row-major, plain adds (oracle order); branch-free update of the running (max, lowest index)
+      float sum = t00;
+      sum = sum + t01;
+      sum = sum + t02;
+      sum = sum + t10;
+      sum = sum + t11;
+      sum = sum + t12;
+      sum = sum + t20;
+      sum = sum + t21;
+      sum = sum + t22;
       const float v = invb ? sum * scale : sum;
-      const bool take = cand_ok && (v > best[it] || (v == best[it] && n < bidx[it]));
+      const bool take = cand_ok & ((v > best[it]) | ((v == best[it]) & (n < bidx[it])));
       best[it] = take ? v : best[it];
       bidx[it] = take ? n : bidx[it];
     }

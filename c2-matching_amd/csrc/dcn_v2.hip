@@ -84,17 +84,27 @@ __device__ __forceinline__ float tap_sample(const Tap& t, const float* __restric
 // ---------------------------------------------------------------------------------------------------------------------
 // weight re-layout: W[Co][C][T] -> Wt[k][CoPad] (forward A operand rows) and Wb[CoPad2][KtotPad] (backward-data A operand)
 // ---------------------------------------------------------------------------------------------------------------------
+// nhwc_order != 0 selects the K order of the channels-last forward kernel instead:
+//   k = (tap * dg + g) * CPG + kk,  kk = 2t + hi  <->  channel-in-group t + hi * CPG/2
 __global__ void __launch_bounds__(256) weight_relayout_kernel(const float* __restrict__ w, Geom g, int CoPad2,
-                                                               float* __restrict__ wt, float* __restrict__ wb) {
+                                                               int nhwc_order, float* __restrict__ wt,
+                                                               float* __restrict__ wb) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int rows = max(g.CoPad, CoPad2);
   if (e >= rows * g.KtotPad) return;
   const int o = e / g.KtotPad, k = e - o * g.KtotPad;
   float v = 0.0f;
   if (o < g.Co && k < g.Ktot) {
-    const int gt = k / g.CPG, cig = k - gt * g.CPG;
-    const int grp = gt / g.T, tap = gt - grp * g.T;
-    v = w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap];
+    if (nhwc_order) {
+      const int tg = k / g.CPG, kk = k - tg * g.CPG;
+      const int tap = tg / g.dg, grp = tg - tap * g.dg;
+      const int cig = (kk >> 1) + (kk & 1) * (g.CPG / 2);
+      v = w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap];
+    } else {
+      const int gt = k / g.CPG, cig = k - gt * g.CPG;
+      const int grp = gt / g.T, tap = gt - grp * g.T;
+      v = w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap];
+    }
   }
   if (wt && o < g.CoPad) wt[(size_t)k * g.CoPad + o] = v;
   if (wb && o < CoPad2) wb[(size_t)o * g.KtotPad + k] = v;
@@ -183,6 +193,126 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_mfma_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// NCHW -> NHWC staging copy (one pass, LDS-tiled transpose).  Patch-match pre-offsets are long range and, on synthetic
+// or textured data, incoherent between neighbouring pixels: in NCHW every (corner, channel) of a gather is its own
+// cache line; channels-last makes one corner = one contiguous C/dg-vector and lets all groups share the pixel's line.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW,
+                                                            float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* ib = in + (size_t)b * C * HW;
+  float* ob = out + (size_t)b * C * HW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, p = p0 + tx;
+    tile[ty + 8 * r][tx] = (c < C && p < HW) ? ib[(size_t)c * HW + p] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = p0 + ty + 8 * r, c = c0 + tx;
+    if (c < C && p < HW) ob[(size_t)p * C + c] = tile[tx][ty + 8 * r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, channels-last gathers: same wave tiling as dcn_fwd_mfma_kernel, K order (tap, group, kk).  Lane (hi, j) owns
+// the contiguous half-run of CPG/2 channels [hi*CPG/2, (hi+1)*CPG/2) of its group: one float4 gather per 4 channels and
+// corner, all taps/groups of a pixel hitting the same few cache lines.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int CPG>
+__global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ offset,
+                                                               const float* __restrict__ mask, Geom g,
+                                                               float* __restrict__ out) {
+  constexpr int HALF = CPG / 2, NQ = HALF / 4;
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = tid >> 6;
+  const int b = blockIdx.y, ob = blockIdx.z;
+  const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+  const int p0 = (blockIdx.x * 4 + wv) * (NT * 32);
+  if (p0 >= HWo) return;
+  const float* in_b = inl + (size_t)b * g.C * HW;
+  const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
+  const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
+  const float* wt_o = wt + ob * (MT * 32) + j;
+
+  int py[NT], px[NT], pc[NT];
+  bool pok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int p = p0 + nt * 32 + j;
+    pok[nt] = p < HWo;
+    pc[nt] = min(p, HWo - 1);
+    py[nt] = pc[nt] / g.Wo;
+    px[nt] = pc[nt] - py[nt] * g.Wo;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  for (int tap = 0; tap < g.T; ++tap) {
+    for (int grp = 0; grp < g.dg; ++grp) {
+      float col[NT][HALF];
+      const int coff = grp * CPG + hi * HALF;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Tap tp = make_tap(g, off_b, msk_b, grp, tap, py[nt], px[nt], pc[nt], pok[nt]);
+        const float* q1 = in_b + (size_t)tp.a1 * g.C + coff;
+        const float* q2 = in_b + (size_t)tp.a2 * g.C + coff;
+        const float* q3 = in_b + (size_t)tp.a3 * g.C + coff;
+        const float* q4 = in_b + (size_t)tp.a4 * g.C + coff;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+          const f32x4 v1 = tp.c1 != 0.0f ? *reinterpret_cast<const f32x4*>(q1 + 4 * q) : z;
+          const f32x4 v2 = tp.c2 != 0.0f ? *reinterpret_cast<const f32x4*>(q2 + 4 * q) : z;
+          const f32x4 v3 = tp.c3 != 0.0f ? *reinterpret_cast<const f32x4*>(q3 + 4 * q) : z;
+          const f32x4 v4 = tp.c4 != 0.0f ? *reinterpret_cast<const f32x4*>(q4 + 4 * q) : z;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            col[nt][4 * q + e] = (tp.w1 * v1[e] + tp.w2 * v2[e] + tp.w3 * v3[e] + tp.w4 * v4[e]) * tp.mk;
+        }
+      }
+      const float* wrow = wt_o + (size_t)((tap * g.dg + grp) * CPG + hi) * g.CoPad;
+#pragma unroll
+      for (int t = 0; t < HALF; ++t) {
+        const float* wr = wrow + (size_t)(2 * t) * g.CoPad;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = wr[mt * 32];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, col[nt][t], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* out_b = out + (size_t)b * g.Co * HWo;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (o < g.Co) {
+        const float bo = bias[o];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (pok[nt]) out_b[(size_t)o * HWo + p0 + nt * 32 + j] = acc[mt][nt][r] + bo;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward (data): dCol = W^T . gO per 32(k) x 32(pixel) tile on MFMA, then grad_mask / grad_offset / grad_input
 // COH = CoPad2 / 2 = number of k-pairs of the reduction over output channels (gO tile lives in COH registers)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -219,8 +349,12 @@ __global__ void __launch_bounds__(256) dcn_bwd_data_kernel(const float* __restri
     gq[t] = (o < g.Co && pok) ? go_b[(size_t)o * HWo + pc] : 0.0f;
   }
 
+  // k tiles are independent (their gradients accumulate atomically): blockIdx.z splits them so that small batches
+  // (training: 4 samples per GPU at 40x40 LR) still fill the 256 CUs
   const int nkt = g.KtotPad / 32;
-  for (int kt = 0; kt < nkt; ++kt) {
+  const int kt_per = (nkt + gridDim.z - 1) / gridDim.z;
+  const int kt_end = min(nkt, (int)(blockIdx.z + 1) * kt_per);
+  for (int kt = blockIdx.z * kt_per; kt < kt_end; ++kt) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -462,6 +596,29 @@ inline int copad_fwd(int Co) {
 }
 inline int copad2(int Co) { return Co <= 64 ? 64 : Co <= 128 ? 128 : Co <= 256 ? 256 : -1; }
 
+template <int MT, int NT, int CPG>
+void launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
+                     const float* msk, const Geom& g, float* out) {
+  const int HWo = g.Ho * g.Wo;
+  dim3 grid(ceil_div(HWo, 4 * NT * 32), g.B, g.CoPad / (MT * 32));
+  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG>), grid, dim3(256), 0, st, inl, wt, bias, off, msk, g, out);
+}
+
+template <int CPG>
+void dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt, const float* bias, const float* off,
+                       const float* msk, const Geom& g, float* out) {
+  // pixel tiles per wave: as many as fit next to MT*NT*16 accumulators + NT*CPG/2 column values without spilling
+  constexpr int NT4 = (CPG == 32) ? 1 : 2;
+  switch (mt) {
+    case 1: launch_fwd_nhwc<1, 2, CPG>(st, inl, wt, bias, off, msk, g, out); break;
+    case 2: launch_fwd_nhwc<2, 2, CPG>(st, inl, wt, bias, off, msk, g, out); break;
+    case 4: launch_fwd_nhwc<4, NT4, CPG>(st, inl, wt, bias, off, msk, g, out); break;
+    default: launch_fwd_nhwc<8, 1, CPG>(st, inl, wt, bias, off, msk, g, out); break;
+  }
+}
+
+inline bool use_nhwc(const Geom& g) { return g.CPG == 8 || g.CPG == 16 || g.CPG == 32; }
+
 template <int MT, int NT>
 void launch_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, const float* off, const float* msk,
                 const Geom& g, float* out) {
@@ -474,7 +631,9 @@ void launch_fwd(hipStream_t st, const float* in, const float* wt, const float* b
 extern "C" size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int dg) {
   Geom g;
   if (make_geom(g, B, C, H, W, Co, kh, kw, 1, 1, kh, kw, 1, 1, dg) != C2M_OK) return 0;
-  return align256(sizeof(float) * (size_t)g.KtotPad * copad_fwd(Co));
+  size_t n = align256(sizeof(float) * (size_t)g.KtotPad * copad_fwd(Co));
+  if (use_nhwc(g)) n += align256(sizeof(float) * (size_t)B * C * H * W);  // channels-last staging copy of the input
+  return n;
 }
 
 extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
@@ -487,14 +646,27 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
   if (rc != C2M_OK) return rc;
   if (g.CPG % 2 != 0) return C2M_ERR_UNSUPPORTED;  // k-pairs of the fp32 MFMA never straddle a (group, tap)
   g.CoPad = copad_fwd(Co);
-  const size_t need = align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
+  const bool nhwc = use_nhwc(g);
+  const size_t wbytes = align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
+  const size_t need = wbytes + (nhwc ? align256(sizeof(float) * (size_t)B * C * H * W) : 0);
   if (!workspace || workspace_bytes < need) return C2M_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   float* wt = static_cast<float*>(workspace);
+  float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
+  if (nhwc)
+    hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), B), dim3(256), 0, st, input, C,
+                       H * W, inl);
   hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, g, 0,
-                     wt, (float*)nullptr);
+                     nhwc ? 1 : 0, wt, (float*)nullptr);
   if ((rc = check_launch()) != C2M_OK) return rc;
-  {
+  if (nhwc) {
+    ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
+    switch (g.CPG) {
+      case 8: dispatch_fwd_nhwc<8>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+      case 16: dispatch_fwd_nhwc<16>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+      default: dispatch_fwd_nhwc<32>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+    }
+  } else {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
     switch (fwd_mt(Co)) {
       case 1: launch_fwd<1, 4>(st, input, wt, bias, offset, mask, g, output); break;
@@ -569,11 +741,14 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
 
   hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(max(g.CoPad, ws.CoPad2) * g.KtotPad, 256)), dim3(256), 0,
-                     st, weight, g, ws.CoPad2, (float*)nullptr, wb);
+                     st, weight, g, ws.CoPad2, 0, (float*)nullptr, wb);
   if ((rc = check_launch()) != C2M_OK) return rc;
   {
     ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
-    dim3 grid(ceil_div(HWo, 128), B);
+    const int nkt = g.KtotPad / 32;
+    int nz = ceil_div(2048, ceil_div(HWo, 128) * B);
+    nz = nz < 1 ? 1 : (nz > nkt ? nkt : nz);
+    dim3 grid(ceil_div(HWo, 128), B, nz);
     switch (ws.CoPad2) {
       case 64: hipLaunchKernelGGL((dcn::dcn_bwd_data_kernel<32>), grid, dim3(256), 0, st, input, wb, offset, mask, grad_output, g, grad_input, grad_offset, grad_mask); break;
       case 128: hipLaunchKernelGGL((dcn::dcn_bwd_data_kernel<64>), grid, dim3(256), 0, st, input, wb, offset, mask, grad_output, g, grad_input, grad_offset, grad_mask); break;
