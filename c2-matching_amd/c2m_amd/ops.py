@@ -128,7 +128,7 @@ def dcn_v2_backward(inp, weight, bias, offset, mask, grad_output, stride=1, padd
 
 def dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, kernel_taps, abs_sum=None):
     """conv_offset_mask output [B,3*dg*K,H,W] (+ pre_offset [B,K,H,W,2] or None) -> (offset [B,2*dg*K,H,W], mask
-    [B,dg*K,H,W]) as dcn_v2.py:229-245 builds them; abs_sum (float64 GPU scalar) accumulates sum|learned offset|."""
+    [B,dg*K,H,W]) as dcn_v2.py:229-245 builds them; abs_sum (float64 GPU tensor of 256 slots, zeroed by the caller) accumulates sum|learned offset| across its slots."""
     conv_out = _dev_f32(conv_out, "conv_out")
     B, C3, H, W = conv_out.shape
     dg, K = int(deformable_groups), int(kernel_taps)
@@ -138,6 +138,8 @@ def dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, kernel_taps, abs_s
         pre_offset = _dev_f32(pre_offset, "pre_offset")
         if tuple(pre_offset.shape) != (B, K, H, W, 2):
             raise _lib.C2MError("pre_offset must be [B, K, H, W, 2]")
+    if abs_sum is not None and (abs_sum.dtype != torch.float64 or abs_sum.numel() < 256 or not abs_sum.is_cuda):
+        raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
     offset = torch.empty((B, 2 * dg * K, H, W), dtype=torch.float32, device=conv_out.device)
     mask = torch.empty((B, dg * K, H, W), dtype=torch.float32, device=conv_out.device)
     with torch.cuda.device(conv_out.device):

@@ -163,8 +163,8 @@ constexpr int NIT = (NQP + 15) / 16;  // 13 tap-sum rounds: 16 query patches per
 template <int C>
 __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const float* __restrict__ fin, const float* __restrict__ fref, int Hq, int Wq, int Hr, int Wr, int tiles_y,
-    int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int64_t* __restrict__ max_idx,
-    float* __restrict__ max_val) {
+    int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int is_norm, int norm_input,
+    int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
   using namespace corr;
   constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
   constexpr int KPG = (KP + NIT - 1) / NIT;    // k-pairs issued between two tap-sum rounds
@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 
   const float* fi = fin + (size_t)b * C * Hq * Wq;
   const float* fr = fref + (size_t)b * C * Hr * Wr;
-  const float* invb = inv ? inv + (size_t)b * Hrp * Wrp : nullptr;
+  // `inv` is always a valid global pointer (workspace); is_norm says whether it holds the ref-patch inverse norms
+  // (a pointer selected against nullptr degrades the load to FLAT, which shares lgkmcnt with the LDS reads)
+  const bool has_inv = is_norm != 0;
+  const float* __restrict__ invb = inv + (size_t)b * Hrp * Wrp;
 
   // ---- resident A operands: lane (i = l&31, k = l>>5) of k-pair t holds in[2t + k][tile pixel 32w + i] ----
   float qreg[KP];
@@ -246,6 +249,14 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     if (yn == Hr) { yn = 0; xtn = xt + 1; }
     if (s + 1 < S) issue_row(xtn, yn, (s + 1) & 1);
 
+    // candidate handled by the NEXT iteration: the patch row completed by THIS step (row y of x-tile xt).  Its inverse
+    // norm is fetched now, a whole step before it is needed, so the load never sits in front of barrier (B).
+    const int ncol_nx = xt * WP + j32;
+    const bool cand_nx = (s < S) && (y >= 2) && (j32 < WP) && (ncol_nx < Wrp);
+    const int n_nx = (y - 2) * Wrp + ncol_nx;
+    scale_next = 1.0f;
+    if (has_inv && cand_nx) scale_next = invb[n_nx];
+
     const int sl1 = (sl0 == 2) ? 0 : sl0 + 1;
     const int sl2 = (sl1 == 2) ? 0 : sl1 + 1;
     const float* r0 = ring + sl0 * SLAB;                 // ref row ry     (tap row i = 0)
@@ -281,20 +292,14 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       sum = sum + t20;
       sum = sum + t21;
       sum = sum + t22;
-      const float v = invb ? sum * scale : sum;
+      const float v = has_inv ? sum * scale : sum;
       const bool take = cand_ok & ((v > best[it]) | ((v == best[it]) & (n < bidx[it])));
       best[it] = take ? v : best[it];
       bidx[it] = take ? n : bidx[it];
     }
 
-    // candidate handled by the NEXT iteration: the patch row completed by THIS step (row y of x-tile xt)
-    {
-      const int ncol = xt * WP + j32;
-      cand_ok = (s < S) && (y >= 2) && (j32 < WP) && (ncol < Wrp);
-      n = (y - 2) * Wrp + ncol;
-      scale_next = 1.0f;
-      if (invb && cand_ok) scale_next = invb[n];
-    }
+    cand_ok = cand_nx;
+    n = n_nx;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const int gy = qy0 + qy, gx = qx0 + qx;
     if (j32 == 0 && p < NQP && gy < Hqp && gx < Wqp) {
       const size_t o = (size_t)b * Hqp * Wqp + (size_t)gy * Wqp + gx;
-      if (qden) v = v / qden[o];
+      if (norm_input) v = v / qden[o];
       max_idx[o] = (int64_t)i;
       max_val[o] = v;
     }
@@ -406,7 +411,7 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
   dim3 grid(B * tiles_y * tiles_x);
   ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
   hipLaunchKernelGGL(corr_argmax_mfma_kernel<C>, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y,
-                     tiles_x, inv, qden, max_idx, max_val);
+                     tiles_x, inv ? inv : fin, qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, max_idx, max_val);
   return check_launch();
 }
 }  // namespace

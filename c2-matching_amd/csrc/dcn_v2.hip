@@ -40,15 +40,26 @@ struct Tap {
   bool inside;
 };
 
-__device__ __forceinline__ Tap make_tap(const Geom& g, const float* __restrict__ off_b, const float* __restrict__ msk_b,
-                                        int grp, int tap, int py, int px, int pc, bool pok) {
-  Tap t;
+struct RawTap {
+  float oh, ow, mk;  // offset_h, offset_w, mask of one (pixel, group, tap) as stored by the caller
+};
+
+__device__ __forceinline__ RawTap load_raw_tap(const Geom& g, const float* __restrict__ off_b,
+                                               const float* __restrict__ msk_b, int grp, int tap, int pc) {
   const int HWo = g.Ho * g.Wo;
   const int gt = grp * g.T + tap;
+  RawTap r;
+  r.oh = off_b[(size_t)(2 * gt) * HWo + pc];
+  r.ow = off_b[(size_t)(2 * gt + 1) * HWo + pc];
+  r.mk = msk_b[(size_t)gt * HWo + pc];
+  return r;
+}
+
+__device__ __forceinline__ Tap tap_from_raw(const Geom& g, const RawTap& r, int tap, int py, int px, bool pok) {
+  Tap t;
   const int i = tap / g.kw, j = tap - i * g.kw;
-  const float oh = off_b[(size_t)(2 * gt) * HWo + pc];
-  const float ow = off_b[(size_t)(2 * gt + 1) * HWo + pc];
-  t.mk = pok ? msk_b[(size_t)gt * HWo + pc] : 0.0f;
+  const float oh = r.oh, ow = r.ow;
+  t.mk = pok ? r.mk : 0.0f;
   t.ah = (float)(py * g.sh - g.ph + i * g.dh) + oh;
   t.aw = (float)(px * g.sw - g.pw + j * g.dw) + ow;
   t.inside = pok && t.ah > -1.0f && t.aw > -1.0f && t.ah < (float)g.H && t.aw < (float)g.W;
@@ -69,6 +80,11 @@ __device__ __forceinline__ Tap make_tap(const Geom& g, const float* __restrict__
   const int x0 = min(max(t.wl, 0), g.W - 1), x1 = min(max(wh_, 0), g.W - 1);
   t.a1 = y0 * g.W + x0; t.a2 = y0 * g.W + x1; t.a3 = y1 * g.W + x0; t.a4 = y1 * g.W + x1;
   return t;
+}
+
+__device__ __forceinline__ Tap make_tap(const Geom& g, const float* __restrict__ off_b, const float* __restrict__ msk_b,
+                                        int grp, int tap, int py, int px, int pc, bool pok) {
+  return tap_from_raw(g, load_raw_tap(g, off_b, msk_b, grp, tap, pc), tap, py, px, pok);
 }
 
 // dmcn_im2col_bilinear (:25-54): (w1*v1 + w2*v2 + w3*v3 + w4*v4), corners outside the image read as 0
@@ -218,27 +234,32 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// forward, channels-last gathers: same wave tiling as dcn_fwd_mfma_kernel, K order (tap, group, kk).  Lane (hi, j) owns
-// the contiguous half-run of CPG/2 channels [hi*CPG/2, (hi+1)*CPG/2) of its group: one float4 gather per 4 channels and
-// corner, all taps/groups of a pixel hitting the same few cache lines.
+// forward, channels-last gathers + LDS-staged weights.  Wave tiling as dcn_fwd_mfma_kernel, K order (tap, group, kk).
+//   * lane (hi, j) owns the contiguous half-run of CPG/2 channels [hi*CPG/2, (hi+1)*CPG/2) of its group: one float4
+//     gather per 4 channels and corner; all taps/groups of a pixel hit the same few cache lines;
+//   * the weight rows of GC consecutive groups (a "chunk", <= 32 KiB) are DMA'd global->LDS once per workgroup and shared
+//     by its 4 waves as MFMA A operands (double buffered, one barrier per chunk) instead of 1 global load per MFMA;
+//   * the raw offsets/mask of the NEXT (tap, group) are fetched one iteration ahead, so a group's dependent chain is
+//     gather -> bilinear -> MFMA only.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MT, int NT, int CPG>
+template <int MT, int NT, int CPG, int GC>
 __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
                                                                float* __restrict__ out) {
   constexpr int HALF = CPG / 2, NQ = HALF / 4;
+  constexpr int MW = MT * 32;                 // output channels of this workgroup
+  constexpr int CHUNK = GC * CPG * MW;        // floats per weight chunk
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][GC*CPG][MW]
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
-  const int wv = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y, ob = blockIdx.z;
   const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
-  const int p0 = (blockIdx.x * 4 + wv) * (NT * 32);
-  if (p0 >= HWo) return;
+  const int p0 = (blockIdx.x * 4 + wv) * (NT * 32);  // may lie beyond HWo for the last waves: they still hit the barriers
   const float* in_b = inl + (size_t)b * g.C * HW;
   const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
   const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
-  const float* wt_o = wt + ob * (MT * 32) + j;
 
   int py[NT], px[NT], pc[NT];
   bool pok[NT];
@@ -259,41 +280,109 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-  for (int tap = 0; tap < g.T; ++tap) {
-    for (int grp = 0; grp < g.dg; ++grp) {
-      float col[NT][HALF];
-      const int coff = grp * CPG + hi * HALF;
+  // chunk ci = weight rows [ci*GC*CPG, (ci+1)*GC*CPG) of Wt[K][CoPad], columns [ob*MW, ob*MW + MW)
+  auto stage = [&](int ci, int buf) {   // 16-byte pieces, 64 per DMA instruction (wave-uniform LDS base + lane*16)
+    constexpr int NPIECE = CHUNK / 4;
+    for (int pb = wv * 64; pb < NPIECE; pb += 256) {
+      const int piece = pb + l;
+      if (piece < NPIECE) {
+        const int f = piece * 4;          // float index inside the chunk
+        const int row = f / MW, col = f - row * MW;
+        const float* src = wt + (size_t)(ci * GC * CPG + row) * g.CoPad + ob * MW + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wl + buf * CHUNK + pb * 4), 16, 0, 0);
+      }
+    }
+  };
+
+  // Flat sequence of (tap, group) steps gs = tap*dg + grp, software-pipelined two deep:
+  //   raw offsets/mask of step gs+2 are loaded, the sampling state + gathers of step gs+1 are issued, then the
+  //   bilinear blend + MFMAs of step gs run on data requested one step earlier.
+  const int nstep = g.T * g.dg;
+  auto raw_at = [&](int gs, RawTap (&r)[NT]) {
+    const int tap = gs / g.dg, grp = gs - tap * g.dg;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const Tap tp = make_tap(g, off_b, msk_b, grp, tap, py[nt], px[nt], pc[nt], pok[nt]);
-        const float* q1 = in_b + (size_t)tp.a1 * g.C + coff;
-        const float* q2 = in_b + (size_t)tp.a2 * g.C + coff;
-        const float* q3 = in_b + (size_t)tp.a3 * g.C + coff;
-        const float* q4 = in_b + (size_t)tp.a4 * g.C + coff;
+    for (int nt = 0; nt < NT; ++nt) r[nt] = load_raw_tap(g, off_b, msk_b, grp, tap, pc[nt]);
+  };
+  struct Gath { f32x4 v1[NQ], v2[NQ], v3[NQ], v4[NQ]; };
+  auto gather = [&](int gs, const Tap (&tp)[NT], Gath (&gv)[NT]) {
+    const int tap = gs / g.dg, grp = gs - tap * g.dg;
+    const int coff = grp * CPG + hi * HALF;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-          const f32x4 v1 = tp.c1 != 0.0f ? *reinterpret_cast<const f32x4*>(q1 + 4 * q) : z;
-          const f32x4 v2 = tp.c2 != 0.0f ? *reinterpret_cast<const f32x4*>(q2 + 4 * q) : z;
-          const f32x4 v3 = tp.c3 != 0.0f ? *reinterpret_cast<const f32x4*>(q3 + 4 * q) : z;
-          const f32x4 v4 = tp.c4 != 0.0f ? *reinterpret_cast<const f32x4*>(q4 + 4 * q) : z;
+    for (int nt = 0; nt < NT; ++nt) {
+      const float* q1 = in_b + (size_t)tp[nt].a1 * g.C + coff;
+      const float* q2 = in_b + (size_t)tp[nt].a2 * g.C + coff;
+      const float* q3 = in_b + (size_t)tp[nt].a3 * g.C + coff;
+      const float* q4 = in_b + (size_t)tp[nt].a4 * g.C + coff;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            col[nt][4 * q + e] = (tp.w1 * v1[e] + tp.w2 * v2[e] + tp.w3 * v3[e] + tp.w4 * v4[e]) * tp.mk;
+      for (int q = 0; q < NQ; ++q) {  // clamped addresses are always readable; validity is applied in the blend
+        gv[nt].v1[q] = *reinterpret_cast<const f32x4*>(q1 + 4 * q);
+        gv[nt].v2[q] = *reinterpret_cast<const f32x4*>(q2 + 4 * q);
+        gv[nt].v3[q] = *reinterpret_cast<const f32x4*>(q3 + 4 * q);
+        gv[nt].v4[q] = *reinterpret_cast<const f32x4*>(q4 + 4 * q);
+      }
+    }
+  };
+
+  RawTap raw[NT];
+  Tap tp_cur[NT];
+  Gath gv_cur[NT];
+  raw_at(0, raw);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) tp_cur[nt] = tap_from_raw(g, raw[nt], 0, py[nt], px[nt], pok[nt]);
+  gather(0, tp_cur, gv_cur);
+  if (nstep > 1) raw_at(1, raw);
+  stage(0, 0);
+
+  for (int gs = 0; gs < nstep; ++gs) {
+    const int ci = gs / GC, gi = gs - ci * GC;
+    if (gi == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // chunk ci landed in wl[ci&1]; every wave is done reading wl[(ci+1)&1]
+      if ((ci + 1) * GC < nstep) stage(ci + 1, (ci + 1) & 1);
+    }
+    // (a) sampling state + gathers of step gs+1, raw offsets of step gs+2
+    Tap tp_nx[NT];
+    Gath gv_nx[NT];
+    if (gs + 1 < nstep) {
+      const int tap1 = (gs + 1) / g.dg;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) tp_nx[nt] = tap_from_raw(g, raw[nt], tap1, py[nt], px[nt], pok[nt]);
+      gather(gs + 1, tp_nx, gv_nx);
+      if (gs + 2 < nstep) raw_at(gs + 2, raw);
+    }
+    // (b) blend step gs: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask, corners outside the image read as 0 (:25-54, :189)
+    float col[NT][HALF];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v1 = tp_cur[nt].c1 != 0.0f ? gv_cur[nt].v1[q][e] : 0.0f;
+          const float v2 = tp_cur[nt].c2 != 0.0f ? gv_cur[nt].v2[q][e] : 0.0f;
+          const float v3 = tp_cur[nt].c3 != 0.0f ? gv_cur[nt].v3[q][e] : 0.0f;
+          const float v4 = tp_cur[nt].c4 != 0.0f ? gv_cur[nt].v4[q][e] : 0.0f;
+          col[nt][4 * q + e] =
+              (tp_cur[nt].w1 * v1 + tp_cur[nt].w2 * v2 + tp_cur[nt].w3 * v3 + tp_cur[nt].w4 * v4) * tp_cur[nt].mk;
         }
       }
-      const float* wrow = wt_o + (size_t)((tap * g.dg + grp) * CPG + hi) * g.CoPad;
+    }
+    // (c) MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
+    const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
 #pragma unroll
-      for (int t = 0; t < HALF; ++t) {
-        const float* wr = wrow + (size_t)(2 * t) * g.CoPad;
+    for (int t = 0; t < HALF; ++t) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float a = wr[mt * 32];
+      for (int mt = 0; mt < MT; ++mt) {
+        const float a = wrow[(2 * t) * MW + mt * 32];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, col[nt][t], acc[mt][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, col[nt][t], acc[mt][nt], 0, 0, 0);
       }
+    }
+    if (gs + 1 < nstep) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { tp_cur[nt] = tp_nx[nt]; gv_cur[nt] = gv_nx[nt]; }
     }
   }
 
@@ -302,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = ob * (MT * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int o = ob * MW + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (o < g.Co) {
         const float bo = bias[o];
 #pragma unroll
@@ -522,27 +611,34 @@ __global__ void __launch_bounds__(256) dcn_bias_grad_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------------
 // offset / mask assembly of DCN_sep_pre_multi_offset.forward (dcn_v2.py:229-245) in one pass
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kAbsSlots = 256;  // abs_sum is an array of this many doubles: spreads the atomics of ~10^5 workgroups
+constexpr int kFusePix = 4;     // pixels per thread
+
 __global__ void __launch_bounds__(256) fuse_offsets_kernel(const float* __restrict__ conv_out,
                                                             const float2* __restrict__ pre, int dg, int K, int HW,
                                                             float* __restrict__ offset, float* __restrict__ mask,
                                                             double* __restrict__ abs_sum) {
   __shared__ float red[256];
-  const int p = blockIdx.x * 256 + threadIdx.x;
   const int ch = blockIdx.y, b = blockIdx.z;  // ch over 3*dg*K conv channels
   const int n2 = 2 * dg * K;
+  const float* src = conv_out + ((size_t)b * 3 * dg * K + ch) * HW;
   float a = 0.0f;
-  if (p < HW) {
-    const float v = conv_out[((size_t)b * 3 * dg * K + ch) * HW + p];
-    if (ch < n2) {
-      float add = 0.0f;
-      if (pre) {
-        const float2 f = pre[((size_t)b * K + (ch >> 1) % K) * HW + p];  // (x, y); even offset channels are dy
-        add = (ch & 1) ? f.x : f.y;
+#pragma unroll
+  for (int e = 0; e < kFusePix; ++e) {
+    const int p = (blockIdx.x * kFusePix + e) * 256 + threadIdx.x;
+    if (p < HW) {
+      const float v = src[p];
+      if (ch < n2) {
+        float add = 0.0f;
+        if (pre) {
+          const float2 f = pre[((size_t)b * K + (ch >> 1) % K) * HW + p];  // (x, y); even offset channels are dy
+          add = (ch & 1) ? f.x : f.y;
+        }
+        offset[((size_t)b * n2 + ch) * HW + p] = v + add;
+        a += fabsf(v);
+      } else {
+        mask[((size_t)b * dg * K + (ch - n2)) * HW + p] = 1.0f / (1.0f + expf(-v));
       }
-      offset[((size_t)b * n2 + ch) * HW + p] = v + add;
-      a = fabsf(v);
-    } else {
-      mask[((size_t)b * dg * K + (ch - n2)) * HW + p] = 1.0f / (1.0f + expf(-v));
     }
   }
   if (abs_sum && ch < n2) {
@@ -552,7 +648,7 @@ __global__ void __launch_bounds__(256) fuse_offsets_kernel(const float* __restri
       if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
       __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(abs_sum, (double)red[0]);
+    if (threadIdx.x == 0) atomicAdd(abs_sum + ((blockIdx.x * 31 + blockIdx.y * 7 + blockIdx.z) & (kAbsSlots - 1)), (double)red[0]);
   }
 }
 
@@ -596,24 +692,53 @@ inline int copad_fwd(int Co) {
 }
 inline int copad2(int Co) { return Co <= 64 ? 64 : Co <= 128 ? 128 : Co <= 256 ? 256 : -1; }
 
-template <int MT, int NT, int CPG>
-void launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
-                     const float* msk, const Geom& g, float* out) {
+template <int MT, int NT, int CPG, int GC>
+int launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
+                    const float* msk, const Geom& g, float* out) {
   const int HWo = g.Ho * g.Wo;
+  const size_t lds = sizeof(float) * 2 * (size_t)GC * CPG * MT * 32;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
+    attr_set = true;
+  }
   dim3 grid(ceil_div(HWo, 4 * NT * 32), g.B, g.CoPad / (MT * 32));
-  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG>), grid, dim3(256), 0, st, inl, wt, bias, off, msk, g, out);
+  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
+  return C2M_OK;
+}
+
+// groups per weight chunk: the largest power of two dividing dg with chunk <= 32 KiB (and >= 4 KiB so that every wave's
+// quarter is a whole number of 1 KiB DMA pieces)
+template <int MT, int NT, int CPG>
+int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
+                     const float* msk, const Geom& g, float* out) {
+  constexpr int ROWB = CPG * MT * 32 * 4;  // bytes of one group's weight rows
+  constexpr int FIT = (32 * 1024) / ROWB;  // groups that fit a 32 KiB chunk (>= 1 for every instantiation)
+  if constexpr (FIT >= 8) {
+    if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8>(st, inl, wt, bias, off, msk, g, out);
+  }
+  if constexpr (FIT >= 4) {
+    if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4>(st, inl, wt, bias, off, msk, g, out);
+  }
+  if constexpr (FIT >= 2) {
+    if (g.dg % 2 == 0) return launch_fwd_nhwc<MT, NT, CPG, 2>(st, inl, wt, bias, off, msk, g, out);
+  }
+  return launch_fwd_nhwc<MT, NT, CPG, 1>(st, inl, wt, bias, off, msk, g, out);
 }
 
 template <int CPG>
-void dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt, const float* bias, const float* off,
-                       const float* msk, const Geom& g, float* out) {
-  // pixel tiles per wave: as many as fit next to MT*NT*16 accumulators + NT*CPG/2 column values without spilling
-  constexpr int NT4 = (CPG == 32) ? 1 : 2;
+int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt, const float* bias, const float* off,
+                      const float* msk, const Geom& g, float* out) {
+  // Register budget (256 VGPRs at 2 waves/SIMD): MT*NT*16 accumulators + two generations of gathered corners
+  // (NT*4*CPG/2 values each) + column values.  Co > 128 is split over grid.z (each workgroup re-gathers: cheap next to
+  // the MFMA work of >= 128 output channels).
+  constexpr int NT2 = (CPG == 8) ? 2 : 1;
   switch (mt) {
-    case 1: launch_fwd_nhwc<1, 2, CPG>(st, inl, wt, bias, off, msk, g, out); break;
-    case 2: launch_fwd_nhwc<2, 2, CPG>(st, inl, wt, bias, off, msk, g, out); break;
-    case 4: launch_fwd_nhwc<4, NT4, CPG>(st, inl, wt, bias, off, msk, g, out); break;
-    default: launch_fwd_nhwc<8, 1, CPG>(st, inl, wt, bias, off, msk, g, out); break;
+    case 1: return pick_gc_fwd_nhwc<1, NT2, CPG>(st, inl, wt, bias, off, msk, g, out);
+    case 2: return pick_gc_fwd_nhwc<2, NT2, CPG>(st, inl, wt, bias, off, msk, g, out);
+    default: return pick_gc_fwd_nhwc<4, 1, CPG>(st, inl, wt, bias, off, msk, g, out);
   }
 }
 
@@ -662,10 +787,11 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
   if (nhwc) {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
     switch (g.CPG) {
-      case 8: dispatch_fwd_nhwc<8>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
-      case 16: dispatch_fwd_nhwc<16>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
-      default: dispatch_fwd_nhwc<32>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+      case 8: rc = dispatch_fwd_nhwc<8>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+      case 16: rc = dispatch_fwd_nhwc<16>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+      default: rc = dispatch_fwd_nhwc<32>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
     }
+    if (rc != C2M_OK) return rc;
   } else {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
     switch (fwd_mt(Co)) {
@@ -784,7 +910,7 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
 extern "C" int c2m_dcn_fuse_offsets_f32(c2m_stream_t stream, const float* conv_out, const float* pre_offset, int B,
                                         int dg, int K, int H, int W, float* offset, float* mask, double* abs_sum) {
   if (!conv_out || !offset || !mask || B <= 0 || dg <= 0 || K <= 0 || H <= 0 || W <= 0) return C2M_ERR_INVALID_ARG;
-  dim3 grid(ceil_div(H * W, 256), 3 * dg * K, B);
+  dim3 grid(ceil_div(H * W, 256 * dcn::kFusePix), 3 * dg * K, B);
   hipLaunchKernelGGL(dcn::fuse_offsets_kernel, grid, dim3(256), 0, as_stream(stream), conv_out,
                      reinterpret_cast<const float2*>(pre_offset), dg, K, H * W, offset, mask, abs_sum);
   return check_launch();

@@ -22,6 +22,7 @@ from torch.nn.modules.utils import _pair
 from c2m_amd import ops as _ops
 
 logger = logging.getLogger('base')
+_ABS_SLOTS = 256  # C2M_ABS_SUM_SLOTS of include/c2m_hip.h
 
 
 class _DCNv2(Function):
@@ -75,14 +76,14 @@ class _OffsetMeanWatch:
         if self._pending is not None:
             host, event, numel = self._pending
             if event.query():
-                mean = float(host.item()) / numel
+                mean = float(host.sum()) / numel
                 if mean > 100:
                     logger.warning('Offset mean is {}, larger than 100.'.format(mean))
                 self._pending = None
 
     def push(self, abs_sum, numel):
         if self._pending is None:
-            host = torch.empty(1, dtype=torch.float64, pin_memory=True)
+            host = torch.empty(_ABS_SLOTS, dtype=torch.float64, pin_memory=True)
             host.copy_(abs_sum, non_blocking=True)
             event = torch.cuda.Event()
             event.record()
@@ -148,7 +149,7 @@ class _SelfOffsetDCN(DCNv2):
         abs_sum = None
         if watch:
             self._watch.poll()
-            abs_sum = torch.zeros(1, dtype=torch.float64, device=raw.device)
+            abs_sum = torch.zeros(_ABS_SLOTS, dtype=torch.float64, device=raw.device)
         offset, mask = _FusedOffsets.apply(raw, pre_offset, self.deformable_groups, self._taps, abs_sum)
         if watch:
             self._watch.push(abs_sum, offset.numel())

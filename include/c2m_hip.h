@@ -114,9 +114,11 @@ int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, const float
  * conv_out [B][3*dg*K][H][W] (raw output of conv_offset_mask, K = kh*kw), pre_offset [B][K][H][W][2] (x, y) or NULL ->
  *   offset [B][2*dg*K][H][W] = cat(o1, o2) + interleaved (y, x) pre-offset repeated over the dg groups
  *   mask   [B][dg*K][H][W]   = sigmoid(third chunk)
- *   abs_sum (device double, may be NULL): accumulates sum |cat(o1,o2)| for the reference's "offset mean > 100" warning
- *   without a host sync in the hot path (caller zeroes it).
+ *   abs_sum (device double[C2M_ABS_SUM_SLOTS], may be NULL): the slots together accumulate sum |cat(o1,o2)| for the
+ *   reference's "offset mean > 100" warning without a host sync in the hot path (caller zeroes them and adds them up;
+ *   many slots so that ~10^5 workgroups do not serialise on one atomic).
  */
+#define C2M_ABS_SUM_SLOTS 256
 int c2m_dcn_fuse_offsets_f32(c2m_stream_t stream, const float* conv_out, const float* pre_offset, int B, int dg, int K,
                              int H, int W, float* offset, float* mask, double* abs_sum);
 

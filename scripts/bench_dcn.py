@@ -79,13 +79,13 @@ def main():
                                    "tflops": flops / ms / 1e9, "frac_fp32_mfma_peak": flops / ms / 1e9 / PEAK})
             del x, w, b, off, msk
             torch.cuda.empty_cache()
-    for name, C, s in (("small", 256, 1), ("medium", 128, 2), ("large", 64, 4)):
+    for flow, name, C, s in [(f, *l) for f in ("random", "blocks") for l in (("small", 256, 1), ("medium", 128, 2), ("large", 64, 4))]:
         H = args.bwd_lr * s
-        x, w, b, off, msk = make_inputs(args.bwd_batch, C, H, 8, dev, 2, args.bwd_lr)
+        x, w, b, off, msk = make_inputs(args.bwd_batch, C, H, 8, dev, 2, args.bwd_lr, flow)
         go = torch.randn_like(x)
         t = timed(lambda: ops.dcn_v2_backward(x, w, b, off, msk, go, 1, 1, 1, 8), args.iters, name)
         flops = 2.0 * C * 9 * C * H * H * args.bwd_batch
-        res["backward"].append({"layer": name, "C": C, "H": H, "B": args.bwd_batch,
+        res["backward"].append({"layer": name, "flow": flow, "C": C, "H": H, "B": args.bwd_batch,
                                 "data_ms": t.get("dcn_v2_backward_data"), "weight_ms": t.get("dcn_v2_backward_weight"),
                                 "data_tflops": flops / t["dcn_v2_backward_data"] / 1e9,
                                 "weight_tflops": flops / t["dcn_v2_backward_weight"] / 1e9})

@@ -99,7 +99,7 @@ def test_fuse_offsets_matches_reference_formula(env, dev):
     B, dg, K, H, W = 2, 8, 9, 11, 13
     raw = _t(synth.gaussish((B, 3 * dg * K, H, W), 600), dev)
     pre = _t(np.round(synth.gaussish((B, K, H, W, 2), 601) * 5), dev)
-    abs_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    abs_sum = torch.zeros(256, dtype=torch.float64, device=dev)
     offset, mask = ops.dcn_fuse_offsets(raw, pre, dg, K, abs_sum)
     o1, o2, m = torch.chunk(raw, 3, dim=1)
     want_off = torch.cat((o1, o2), dim=1)
@@ -109,7 +109,7 @@ def test_fuse_offsets_matches_reference_formula(env, dev):
     reorder[:, 1::2] = rep[..., 0]
     assert torch.equal(offset, want_off + reorder)
     assert float((mask - torch.sigmoid(m)).abs().max()) < 1e-6
-    assert abs(float(abs_sum) / want_off.numel() - float(want_off.abs().mean())) < 1e-5
+    assert abs(float(abs_sum.sum()) / want_off.numel() - float(want_off.abs().mean())) < 1e-5
     off2, mask2 = ops.dcn_fuse_offsets(raw, None, dg, K)
     assert torch.equal(off2, want_off) and torch.equal(mask2, mask)
 
