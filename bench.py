@@ -57,32 +57,42 @@ def corr_executed_flops(B, C, h):
     return B * tiles * (steps + 1) * 8 * (C // 2) * (2 * 32 * 32 * 2)
 
 
-def cpu_baseline(h, C, rows=48, threads=None):
+def cpu_baseline(h, C, threads=None, budget_s=12.0):
     """Reference algorithm (ref patches as conv2d filters, chunked running arg-max -- ref_map_util.py:26-86 as restated in
-    oracle/torch_port.py) on PyTorch-CPU, on a bounded sample: `rows` query pixel rows of ONE 160x160 pair against the full
-    ref map; cost is linear in query rows, so pairs/s = (rows-2)/(h-2) / seconds."""
+    oracle/torch_port.py) on PyTorch-CPU.  Bounded sample: `rows` query pixel rows of ONE h x h pair against the full ref map
+    (cost is linear in query rows, pairs/s = (rows-2)/(h-2) / seconds).  A 48-row probe sizes the sample so that it runs
+    for roughly `budget_s` seconds (at most the whole pair)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch_port
     import c2m_oracle
     threads = threads or os.cpu_count()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1234)
-    fi = torch.nn.functional.normalize(torch.randn((C, rows, h), generator=g), dim=0)
+    fi_full = torch.nn.functional.normalize(torch.randn((C, h, h), generator=g), dim=0)
     fr = torch.nn.functional.normalize(torch.randn((C, h, h), generator=g), dim=0)
-    torch_port.feature_match_index_conv(fi[:, :6], fr[:, :12], 3, 1, 1, True, True)  # warm-up
-    t0 = time.perf_counter()
-    torch_port.feature_match_index_conv(fi, fr, 3, 1, 1, True, True)
-    dt = time.perf_counter() - t0
+    torch_port.feature_match_index_conv(fi_full[:, :6], fr[:, :12], 3, 1, 1, True, True)  # warm-up
+
+    def run(rows):
+        t0 = time.perf_counter()
+        torch_port.feature_match_index_conv(fi_full[:, :rows].contiguous(), fr, 3, 1, 1, True, True)
+        return time.perf_counter() - t0
+
+    rows = min(48, h)
+    dt = run(rows)
+    want = int(min(h, max(rows, 2 + (rows - 2) * budget_s / max(dt, 1e-3))))
+    if want > rows + 8:
+        rows = want
+        dt = run(rows)
     frac = (rows - 2) / (h - 2)
-    # the C oracle (pixel-level restructuring, OpenMP) on the same sample, for context
+    # the C oracle (pixel-level restructuring, OpenMP) on a 48-row sample, for context
     c2m_oracle.set_num_threads(min(threads, 32))
     t0 = time.perf_counter()
-    c2m_oracle.feature_match_index(fi.numpy(), fr.numpy(), 3, 1, 1, True, True)
+    c2m_oracle.feature_match_index(fi_full[:, :48].contiguous().numpy(), fr.numpy(), 3, 1, 1, True, True)
     dt_c = time.perf_counter() - t0
     return {"value": frac / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{rows} of {h} query rows of one {h}x{h}x{C} pair vs full ref map, PyTorch-CPU conv2d+max "
-                      f"(reference algorithm), {dt:.2f}s; linear extrapolation to a pair",
-            "oracle_c_openmp_pairs_per_s": frac / dt_c}
+                      f"(reference algorithm, oracle/torch_port.py), {dt:.2f}s; linear extrapolation to a pair",
+            "oracle_c_openmp_pairs_per_s": (46 / (h - 2)) / dt_c, "oracle_c_threads": min(threads, 32)}
 
 
 def main():
