@@ -15,10 +15,12 @@
 //   * the ref map is swept in x-tiles of 32 pixels (30 patches) and, inside an x-tile, one PIXEL ROW per step;
 //     the row segment [C][32] is DMA'd global->LDS (double buffered, global_load_lds) and is the B-operand of
 //     all 8 waves;
-//   * each step yields D[256 query pixels][32 ref pixels] -> a 3-slab LDS ring (rows y-2, y-1, y); once row y is
-//     in, the patch row ry = y-2 is complete: lanes (= ref x) add the nine taps, scale by the precomputed inverse
-//     patch norm and update a per-lane running (max, argmin-index); that VALU/LDS work is interleaved with the
-//     next step's MFMA chain;
+//   * each step yields D[256 query pixels][32 ref pixels]; the three taps of one patch ROW are summed while the tile
+//     is still in the accumulator registers (two DPP wave-shifted adds per element: H[i][j] = D[i][j] + (D[i+1][j+1] +
+//     D[i+2][j+2])), and H goes to a 3-slab LDS ring (ref rows y-2, y-1, y); once row y is in, the patch row
+//     ry = y-2 is complete: lanes (= ref x) add the three row sums, scale by the precomputed inverse patch norm and
+//     update a per-lane running (max, argmin-index).  Every non-MFMA instruction costs matrix time on this chip
+//     (profiles/r01_corr_ablation.json), hence 3 LDS reads + 2 adds per candidate instead of 9 + 8;
 //   * after the sweep a 32-lane shuffle reduction with the (larger value, then lower index) rule yields the
 //     reference's "first maximum" semantics exactly, independent of the visiting order.
 //
@@ -111,13 +113,16 @@ __global__ void __launch_bounds__(256) corr_argmax_generic_kernel(
   for (int n = threadIdx.x; n < Nrp; n += 256) {
     const int ry = n / Wrp, rx = n - ry * Wrp;
     float s = 0.0f;
-    for (int t = 0; t < PP; ++t) {
-      const int i = t / P, j = t - i * P;
-      const float* r = fr + (ry * sr + i) * Wr + rx * sr + j;
-      const float* ql = qlds + t * C;
-      float d = 0.0f;
-      for (int c = 0; c < C; ++c) d = fmaf(ql[c], r[(size_t)c * HWr], d);
-      s = (t == 0) ? d : s + d;
+    for (int i = 0; i < P; ++i) {          // rows left-to-right, taps of a row right-to-left (canonical order)
+      float row = 0.0f;
+      for (int j = P - 1; j >= 0; --j) {
+        const float* r = fr + (ry * sr + i) * Wr + rx * sr + j;
+        const float* ql = qlds + (i * P + j) * C;
+        float d = 0.0f;
+        for (int c = 0; c < C; ++c) d = fmaf(ql[c], r[(size_t)c * HWr], d);
+        row = (j == P - 1) ? d : d + row;
+      }
+      s = (i == 0) ? row : s + row;
     }
     const float v = inv ? s * inv[(size_t)b * Nrp + n] : s;
     if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
@@ -270,28 +275,19 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      // (1) issue the nine tap reads of round `it`; they are consumed only after this round's MFMA group, so their
-      //     LDS latency is covered by ~KPG*64 cycles of matrix work instead of being waited for one by one
+      // (1) issue the three row-sum reads of round `it`; they are consumed only after this round's MFMA group, so
+      //     their LDS latency is covered by ~KPG*64 cycles of matrix work
       const int pb = pbase[it];
-      const float t00 = r0[pb], t01 = r0[pb + WT + 1], t02 = r0[pb + 2 * WT + 2];
-      const float t10 = r1[pb], t11 = r1[pb + WT + 1], t12 = r1[pb + 2 * WT + 2];
-      const float t20 = r2[pb], t21 = r2[pb + WT + 1], t22 = r2[pb + 2 * WT + 2];
+      const float h0 = r0[pb], h1 = r1[pb], h2 = r2[pb];
       __builtin_amdgcn_sched_barrier(0);
       // (2) MFMA group: k-pairs [it*KPG, (it+1)*KPG)
 #pragma unroll
       for (int t = it * KPG; t < (it + 1) * KPG && t < KP; ++t)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      // (3) nine taps, row-major, plain adds (oracle order); branch-free update of the running (max, lowest index)
-      float sum = t00;
-      sum = sum + t01;
-      sum = sum + t02;
-      sum = sum + t10;
-      sum = sum + t11;
-      sum = sum + t12;
-      sum = sum + t20;
-      sum = sum + t21;
-      sum = sum + t22;
+      // (3) (row_0 + row_1) + row_2 (oracle order); branch-free update of the running (max, lowest index)
+      float sum = h0 + h1;
+      sum = sum + h2;
       const float v = has_inv ? sum * scale : sum;
       const bool take = cand_ok & ((v > best[it]) | ((v == best[it]) & (n < bidx[it])));
       best[it] = take ? v : best[it];
@@ -304,11 +300,49 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
 
-    // D tile of this wave -> slab s % 3: rows 32w + i, i = (r&3) + 8*(r>>2) + 4*hi ; column j32
+    // Row sums of the 3 taps of a patch row, formed in registers: lane (hi, j) holds rows i(r) = (r&3) + 8*(r>>2) + 4*hi
+    // of column j.  nxt(V)[r] = V at (row i+1, column j+1): the next register of the same lane shifted by one lane
+    // (DPP wave_shl:1), except for r&3 == 3 where row i+1 lives in the other half-wave (v_permlane32_swap).
+    //   t[r] = D[r] + nxt(D)[r]      = D[i][j] + D[i+1][j+1]
+    //   H[r] = D[r] + nxt(t)[r]      = D[i][j] + (D[i+1][j+1] + D[i+2][j+2])
+    // Elements whose taps would leave the 16-pixel tile row or the 32-column x-tile are never used as patch origins.
+    auto shl1 = [](float x) __attribute__((always_inline)) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
+    };
     {
+      float dv[16], nx[16], tt[16], hh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dv[r] = acc[r];
+      // pass 1: t = D + nxt(D)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // row 4 + 8g + 4hi lives in the other half-wave: hi = 0 wants the partner's V[4g], hi = 1 the partner's V[4(g+1)]
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, dv[4 * g]),
+                                                         __builtin_bit_cast(unsigned, dv[g < 3 ? 4 * g + 4 : 4 * g]),
+                                                         false, false);   // sw[0] = (a.lo, b.lo), sw[1] = (a.hi, b.hi)
+        nx[4 * g + 0] = dv[4 * g + 1];
+        nx[4 * g + 1] = dv[4 * g + 2];
+        nx[4 * g + 2] = dv[4 * g + 3];
+        nx[4 * g + 3] = __builtin_bit_cast(float, hi ? sw[0] : sw[1]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tt[r] = dv[r] + shl1(nx[r]);
+      // pass 2: H = D + nxt(t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tt[4 * g]),
+                                                         __builtin_bit_cast(unsigned, tt[g < 3 ? 4 * g + 4 : 4 * g]),
+                                                         false, false);
+        nx[4 * g + 0] = tt[4 * g + 1];
+        nx[4 * g + 1] = tt[4 * g + 2];
+        nx[4 * g + 2] = tt[4 * g + 3];
+        nx[4 * g + 3] = __builtin_bit_cast(float, hi ? sw[0] : sw[1]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hh[r] = dv[r] + shl1(nx[r]);
       float* dst = ring + sl0 * SLAB + (32 * w + 4 * hi) * WT + j32;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * WT] = acc[r];
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * WT] = hh[r];
     }
 
     y = yn;

@@ -24,7 +24,9 @@
  *
  * Canonical floating-point order of the correlation (the HIP kernels reproduce it bit for bit):
  *   D[p][r]   = fmaf chain over channels c = 0..C-1, starting from +0:  acc = fmaf(in[c][p], ref[c][r], acc)
- *   S[q][n]   = D[q+t0][n+t0] + D[q+t1][n+t1] + ... taps row-major (i outer, j inner), plain fp32 adds
+ *   S[q][n]   = (row_0 + row_1) + ... + row_{P-1},  row_i = t_i0 + (t_i1 + (... + t_i,P-1)) with t_ij = D[q+(i,j)][n+(i,j)]:
+ *               taps of one patch row are added right-to-left, the rows left-to-right, plain fp32 adds (this is the order in
+ *               which the HIP kernel forms the row sums in registers with two DPP shifted adds before parking them in LDS)
  *   ss[pix]   = fmaf chain over c of x*x ;  patch_ss = row-major plain adds of ss over the PxP window
  *   inv[n]    = 1.0f / (sqrtf(patch_ss[n]) + 1e-5f)            (ref_map_util.py:62-63, scale factored out of
  *                                                               the inner product -- differs from the reference's
@@ -189,13 +191,14 @@ int c2m_oracle_feature_match_index(const float* fin, const float* fref, int C, i
         for (int ry = 0; ry < Hrp; ++ry)
           for (int rx = 0; rx < Wrp; ++rx) {
             float s = 0.0f;
-            int first = 1;
             for (int i = 0; i < P; ++i) {
               const float* Dr = ring[(qy * in_stride + i) % P];
-              for (int j = 0; j < P; ++j) {
+              float row = 0.0f;
+              for (int j = P - 1; j >= 0; --j) {
                 float d = Dr[(size_t)(qx * in_stride + j) * Nr + (size_t)(ry * ref_stride + i) * Wr + rx * ref_stride + j];
-                if (first) { s = d; first = 0; } else { s = s + d; }
+                row = (j == P - 1) ? d : d + row;
               }
+              s = (i == 0) ? row : s + row;
             }
             int n = ry * Wrp + rx;
             float v = is_norm ? s * inv[n] : s;
