@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
   using namespace corr;
   constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
+  constexpr int KPG = (KP + NIT - 1) / NIT;    // k-pairs issued between two tap-sum rounds
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;                          // [3][QPIX][WT]
   float* rbuf = smem + 3 * SLAB;               // [2][C][WT]
@@ -221,22 +222,13 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
   const int nxt = (Wrp + WP - 1) / WP;
   const int S = nxt * Hr;
 
-  // DMA of ref pixel row (xt, y) into rbuf[buf].  LDS image per buffer: dword ((m*2 + hi)*32 + j)*4 + e holds channel
-  // 8m + 2e + hi of pixel j, i.e. the B operands of the four consecutive k-pairs t = 4m + e of lane (hi, j) are 16
-  // contiguous bytes (one ds_read_b128 instead of two ds_read2st64).  A DMA instruction fills 64 consecutive dwords
-  // (lane l -> e = l&3, j = 16*(q&1) + (l>>2)); its source addresses are per-lane, so the permutation costs nothing.
-  // Wave w copies the k-groups m in [w*C/64, (w+1)*C/64): C/64 * 8 instructions.
+  // DMA of ref pixel row (xt, y) into rbuf[buf]: wave w copies channels [32w, 32w+32) as 16 x (2 channels x 32 px)
   auto issue_row = [&](int xt, int y, int buf) {
-    const int e = l & 3, jq = l >> 2;
-    const int xa = min(xt * WP + jq, Wr - 1), xb = min(xt * WP + 16 + jq, Wr - 1);
-    const float* g0 = fr + (size_t)(2 * e) * Hr * Wr + (size_t)y * Wr;
+    const int x = min(xt * WP + j32, Wr - 1);
+    const float* g = fr + (size_t)(w * (C / NWAVE) + hi) * Hr * Wr + (size_t)y * Wr + x;
     float* d = rbuf + buf * (C * WT) + w * (C / NWAVE) * WT;
 #pragma unroll
-    for (int q = 0; q < C / NWAVE / 2; ++q) {   // q = (m_local*2 + hi')*2 + jhalf
-      const int mloc = q >> 2, hq = (q >> 1) & 1, jh = q & 1;
-      const float* g = g0 + (size_t)(8 * (w * (C / NWAVE / 8) + mloc) + hq) * Hr * Wr + (jh ? xb : xa);
-      glds_b32(g, d + q * 64);
-    }
+    for (int m = 0; m < C / NWAVE / 2; ++m) glds_b32(g + (size_t)(2 * m) * Hr * Wr, d + (2 * m) * WT);
   };
 
   issue_row(0, 0, 0);
@@ -276,30 +268,22 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const float* r1 = ring + sl1 * SLAB + TQ * WT;       // ref row ry + 1 (i = 1: query pixel row + 1)
     const float* r2 = ring + sl2 * SLAB + 2 * TQ * WT;   // ref row ry + 2 (i = 2)
 
-    // B operands of k-pairs 4m .. 4m+3: one 16-byte read at bsrc4 + m*256 floats (see issue_row)
-    const float* bsrc4 = rbuf + (s & 1) * (C * WT) + l * 4;
+    const float* bsrc = rbuf + (s & 1) * (C * WT) + l;  // B operand of k-pair t: rbuf[2t + hi][j32] = bsrc[t * 64]
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-    auto mfma8 = [&](int g8) __attribute__((always_inline)) {   // k-pairs 8*g8 .. 8*g8+7: two b128 operand reads
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc4 + (2 * g8) * 256);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(bsrc4 + (2 * g8 + 1) * 256);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[8 * g8 + e], b0[e], acc, 0, 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[8 * g8 + 4 + e], b1[e], acc, 0, 0, 0);
-    };
-    static_assert(KP % 8 == 0, "k-pairs are consumed eight at a time");
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       // (1) issue the three row-sum reads of round `it`; they are consumed only after this round's MFMA group, so
-      //     their LDS latency is covered by matrix work
+      //     their LDS latency is covered by ~KPG*64 cycles of matrix work
       const int pb = pbase[it];
       const float h0 = r0[pb], h1 = r1[pb], h2 = r2[pb];
       __builtin_amdgcn_sched_barrier(0);
-      // (2) MFMA group: eight k-pairs per round while there are any
-      if (it < KP / 8) mfma8(it);
+      // (2) MFMA group: k-pairs [it*KPG, (it+1)*KPG)
+#pragma unroll
+      for (int t = it * KPG; t < (it + 1) * KPG && t < KP; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // (3) (row_0 + row_1) + row_2 (oracle order); branch-free update of the running (max, lowest index)
       float sum = h0 + h1;
@@ -309,8 +293,6 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       best[it] = take ? v : best[it];
       bidx[it] = take ? n : bidx[it];
     }
-#pragma unroll
-    for (int g8 = NIT; g8 < KP / 8; ++g8) mfma8(g8);   // the remaining k-pairs (C = 256: 24 of 128)
 
     cand_ok = cand_nx;
     n = n_nx;
