@@ -734,7 +734,9 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
   // Register budget (256 VGPRs at 2 waves/SIMD): MT*NT*16 accumulators + two generations of gathered corners
   // (NT*4*CPG/2 values each) + column values.  Co > 128 is split over grid.z (each workgroup re-gathers: cheap next to
   // the MFMA work of >= 128 output channels).
-  constexpr int NT2 = (CPG == 8) ? 2 : 1;
+  // one pixel tile per wave everywhere: for 8-channel groups that means ~110 VGPRs = 4 waves/SIMD, which hides the gather
+  // latency better than a second pixel tile amortises the LDS weight reads (large layer, B=16: 10.4 -> 8.4 ms)
+  constexpr int NT2 = 1;
   switch (mt) {
     case 1: return pick_gc_fwd_nhwc<1, NT2, CPG>(st, inl, wt, bias, off, msk, g, out);
     case 2: return pick_gc_fwd_nhwc<2, NT2, CPG>(st, inl, wt, bias, off, msk, g, out);
