@@ -55,9 +55,15 @@ __device__ __forceinline__ RawTap load_raw_tap(const Geom& g, const float* __res
   return r;
 }
 
+__device__ __forceinline__ Tap tap_from_raw_ij(const Geom& g, const RawTap& r, int i, int j, int py, int px, bool pok);
+
 __device__ __forceinline__ Tap tap_from_raw(const Geom& g, const RawTap& r, int tap, int py, int px, bool pok) {
-  Tap t;
   const int i = tap / g.kw, j = tap - i * g.kw;
+  return tap_from_raw_ij(g, r, i, j, py, px, pok);
+}
+
+__device__ __forceinline__ Tap tap_from_raw_ij(const Geom& g, const RawTap& r, int i, int j, int py, int px, bool pok) {
+  Tap t;
   const float oh = r.oh, ow = r.ow;
   t.mk = pok ? r.mk : 0.0f;
   t.ah = (float)(py * g.sh - g.ph + i * g.dh) + oh;
@@ -299,76 +305,87 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
   //   raw offsets/mask of step gs+2 are loaded, the sampling state + gathers of step gs+1 are issued, then the
   //   bilinear blend + MFMAs of step gs run on data requested one step earlier.
   const int nstep = g.T * g.dg;
-  auto raw_at = [&](int gs, RawTap (&r)[NT]) {
-    const int tap = gs / g.dg, grp = gs - tap * g.dg;
+  auto raw_at = [&](int tap, int grp, RawTap (&r)[NT]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) r[nt] = load_raw_tap(g, off_b, msk_b, grp, tap, pc[nt]);
   };
   struct Gath { f32x4 v1[NQ], v2[NQ], v3[NQ], v4[NQ]; };
-  auto gather = [&](int gs, const Tap (&tp)[NT], Gath (&gv)[NT]) {
-    const int tap = gs / g.dg, grp = gs - tap * g.dg;
-    const int coff = grp * CPG + hi * HALF;
+  // blend weights of one step: corner validity (:36-47, :180) and the modulation mask (:189) folded into the four
+  // bilinear weights once per (pixel, group, tap) instead of per channel
+  struct Wts { float w1, w2, w3, w4; };
+  auto fold = [&](const Tap& t) {
+    Wts o;
+    o.w1 = t.c1 != 0.0f ? t.w1 * t.mk : 0.0f;
+    o.w2 = t.c2 != 0.0f ? t.w2 * t.mk : 0.0f;
+    o.w3 = t.c3 != 0.0f ? t.w3 * t.mk : 0.0f;
+    o.w4 = t.c4 != 0.0f ? t.w4 * t.mk : 0.0f;
+    return o;
+  };
+  const unsigned lane_ch = hi * HALF;   // this lane's half-run inside its group
+  auto gather = [&](int grp, const Tap (&tp)[NT], Gath (&gv)[NT]) {
+    const float* gb = in_b + grp * CPG;   // wave-uniform base; per-lane part stays a 32-bit element offset
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float* q1 = in_b + (size_t)tp[nt].a1 * g.C + coff;
-      const float* q2 = in_b + (size_t)tp[nt].a2 * g.C + coff;
-      const float* q3 = in_b + (size_t)tp[nt].a3 * g.C + coff;
-      const float* q4 = in_b + (size_t)tp[nt].a4 * g.C + coff;
+      const unsigned o1 = (unsigned)tp[nt].a1 * (unsigned)g.C + lane_ch, o2 = (unsigned)tp[nt].a2 * (unsigned)g.C + lane_ch;
+      const unsigned o3 = (unsigned)tp[nt].a3 * (unsigned)g.C + lane_ch, o4 = (unsigned)tp[nt].a4 * (unsigned)g.C + lane_ch;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {  // clamped addresses are always readable; validity is applied in the blend
-        gv[nt].v1[q] = *reinterpret_cast<const f32x4*>(q1 + 4 * q);
-        gv[nt].v2[q] = *reinterpret_cast<const f32x4*>(q2 + 4 * q);
-        gv[nt].v3[q] = *reinterpret_cast<const f32x4*>(q3 + 4 * q);
-        gv[nt].v4[q] = *reinterpret_cast<const f32x4*>(q4 + 4 * q);
+      for (int q = 0; q < NQ; ++q) {  // clamped addresses are always readable; validity is applied through the weights
+        gv[nt].v1[q] = *reinterpret_cast<const f32x4*>(gb + o1 + 4 * q);
+        gv[nt].v2[q] = *reinterpret_cast<const f32x4*>(gb + o2 + 4 * q);
+        gv[nt].v3[q] = *reinterpret_cast<const f32x4*>(gb + o3 + 4 * q);
+        gv[nt].v4[q] = *reinterpret_cast<const f32x4*>(gb + o4 + 4 * q);
       }
     }
   };
 
-  RawTap raw[NT];
-  Tap tp_cur[NT];
-  Gath gv_cur[NT];
-  raw_at(0, raw);
+  // (tap, group) of steps gs, gs+1, gs+2 are tracked with counters (no integer divisions in the loop)
+  struct Pos { int tap, grp, ti, tj; };
+  auto advance = [&](Pos& p) {
+    if (++p.grp == g.dg) {
+      p.grp = 0;
+      ++p.tap;
+      if (++p.tj == g.kw) { p.tj = 0; ++p.ti; }
+    }
+  };
+  auto state = [&](const RawTap (&r)[NT], const Pos& p, Tap (&tp)[NT]) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) tp_cur[nt] = tap_from_raw(g, raw[nt], 0, py[nt], px[nt], pok[nt]);
-  gather(0, tp_cur, gv_cur);
-  if (nstep > 1) raw_at(1, raw);
-  stage(0, 0);
-
-  for (int gs = 0; gs < nstep; ++gs) {
-    const int ci = gs / GC, gi = gs - ci * GC;
+    for (int nt = 0; nt < NT; ++nt) tp[nt] = tap_from_raw_ij(g, r[nt], p.ti, p.tj, py[nt], px[nt], pok[nt]);
+  };
+  // one pipeline step: issue (state + gathers) of step gs+1 into (tpB, gvB), raw loads of step gs+2, then blend + MFMAs
+  // of step gs from (wA, gvA).  Called alternately with the two register sets swapped, so nothing is ever copied.
+  RawTap raw[NT];
+  Pos p1{0, 0, 0, 0}, p2{0, 0, 0, 0};   // positions of steps gs+1 and gs+2
+  auto step = [&](int gs, Wts (&wA)[NT], Gath (&gvA)[NT], Wts (&wB)[NT], Gath (&gvB)[NT]) __attribute__((always_inline)) {
+    const int ci = gs / GC, gi = gs - ci * GC;   // GC is a power of two
     if (gi == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // chunk ci landed in wl[ci&1]; every wave is done reading wl[(ci+1)&1]
       if ((ci + 1) * GC < nstep) stage(ci + 1, (ci + 1) & 1);
     }
-    // (a) sampling state + gathers of step gs+1, raw offsets of step gs+2
-    Tap tp_nx[NT];
-    Gath gv_nx[NT];
     if (gs + 1 < nstep) {
-      const int tap1 = (gs + 1) / g.dg;
+      Tap tp[NT];
+      state(raw, p1, tp);
+      gather(p1.grp, tp, gvB);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) tp_nx[nt] = tap_from_raw(g, raw[nt], tap1, py[nt], px[nt], pok[nt]);
-      gather(gs + 1, tp_nx, gv_nx);
-      if (gs + 2 < nstep) raw_at(gs + 2, raw);
+      for (int nt = 0; nt < NT; ++nt) wB[nt] = fold(tp[nt]);
+      if (gs + 2 < nstep) raw_at(p2.tap, p2.grp, raw);
+      advance(p1);
+      advance(p2);
     }
-    // (b) blend step gs: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask, corners outside the image read as 0 (:25-54, :189)
+    // blend step gs: w1*v1 + w2*v2 + w3*v3 + w4*v4 with mask and validity already inside the weights (fma chain;
+    // differs from the oracle's (w1*v1 + ... ) * mask by rounding only -- DCNv2 parity is tolerance-based)
     float col[NT][HALF];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v1 = tp_cur[nt].c1 != 0.0f ? gv_cur[nt].v1[q][e] : 0.0f;
-          const float v2 = tp_cur[nt].c2 != 0.0f ? gv_cur[nt].v2[q][e] : 0.0f;
-          const float v3 = tp_cur[nt].c3 != 0.0f ? gv_cur[nt].v3[q][e] : 0.0f;
-          const float v4 = tp_cur[nt].c4 != 0.0f ? gv_cur[nt].v4[q][e] : 0.0f;
-          col[nt][4 * q + e] =
-              (tp_cur[nt].w1 * v1 + tp_cur[nt].w2 * v2 + tp_cur[nt].w3 * v3 + tp_cur[nt].w4 * v4) * tp_cur[nt].mk;
-        }
+        for (int e = 0; e < 4; ++e)
+          col[nt][4 * q + e] = fmaf(wA[nt].w4, gvA[nt].v4[q][e], fmaf(wA[nt].w3, gvA[nt].v3[q][e],
+                               fmaf(wA[nt].w2, gvA[nt].v2[q][e], wA[nt].w1 * gvA[nt].v1[q][e])));
       }
     }
-    // (c) MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
+    // MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
     const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
 #pragma unroll
     for (int t = 0; t < HALF; ++t) {
@@ -380,10 +397,26 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, col[nt][t], acc[mt][nt], 0, 0, 0);
       }
     }
-    if (gs + 1 < nstep) {
+  };
+
+  Wts w0[NT], w1s[NT];
+  Gath gv0[NT], gv1[NT];
+  {
+    Pos p0{0, 0, 0, 0};
+    Tap tp[NT];
+    raw_at(0, 0, raw);
+    state(raw, p0, tp);
+    gather(0, tp, gv0);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { tp_cur[nt] = tp_nx[nt]; gv_cur[nt] = gv_nx[nt]; }
-    }
+    for (int nt = 0; nt < NT; ++nt) w0[nt] = fold(tp[nt]);
+    advance(p1);                 // step 1
+    advance(p2); advance(p2);    // step 2
+    if (nstep > 1) raw_at(p1.tap, p1.grp, raw);
+  }
+  stage(0, 0);
+  for (int gs = 0; gs < nstep; gs += 2) {
+    step(gs, w0, gv0, w1s, gv1);
+    if (gs + 1 < nstep) step(gs + 1, w1s, gv1, w0, gv0);
   }
 
   float* out_b = out + (size_t)b * g.Co * HWo;
