@@ -31,12 +31,13 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
 
 
 def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
-                    dilation_h, dilation_w, deformable_group):
-    """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (new tensors)."""
+                    dilation_h, dilation_w, deformable_group, need_input_grad=True):
+    """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (new tensors).  `need_input_grad=False` (an
+    extension over the reference's signature) skips the col2im scatter and returns None in its place."""
     _check(input, weight, kernel_h, kernel_w)
     try:
         return list(_ops.dcn_v2_backward(input, weight, bias, offset, mask, grad_output, (stride_h, stride_w),
-                                         (pad_h, pad_w), (dilation_h, dilation_w), deformable_group))
+                                         (pad_h, pad_w), (dilation_h, dilation_w), deformable_group, need_input_grad))
     except C2MError as e:
         raise RuntimeError(str(e)) from e
 

@@ -109,7 +109,9 @@ def dcn_v2_forward(inp, weight, bias, offset, mask, stride=1, padding=1, dilatio
     return out
 
 
-def dcn_v2_backward(inp, weight, bias, offset, mask, grad_output, stride=1, padding=1, dilation=1, deformable_groups=1):
+def dcn_v2_backward(inp, weight, bias, offset, mask, grad_output, stride=1, padding=1, dilation=1, deformable_groups=1,
+                    need_input_grad=True):
+    """-> (grad_input or None, grad_offset, grad_mask, grad_weight, grad_bias)."""
     inp, weight, bias, offset, mask, grad_output = (_dev_f32(t, n) for t, n in (
         (inp, "input"), (weight, "weight"), (bias, "bias"), (offset, "offset"), (mask, "mask"), (grad_output, "grad_output")))
     g, Ho, Wo = _dcn_geom(inp, weight, stride, padding, dilation)
@@ -118,10 +120,12 @@ def dcn_v2_backward(inp, weight, bias, offset, mask, grad_output, stride=1, padd
     with torch.cuda.device(inp.device):
         nbytes = L.c2m_dcn_v2_backward_workspace_bytes(*g, dg)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=inp.device)
-        gi, go, gm, gw, gb = (torch.empty_like(t) for t in (inp, offset, mask, weight, bias))
+        go, gm, gw, gb = (torch.empty_like(t) for t in (offset, mask, weight, bias))
+        gi = torch.empty_like(inp) if need_input_grad else None
         _lib.check(L.c2m_dcn_v2_backward_f32(_stream(), inp.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                              offset.data_ptr(), mask.data_ptr(), grad_output.data_ptr(), *g, dg,
-                                             gi.data_ptr(), go.data_ptr(), gm.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                             gi.data_ptr() if gi is not None else None, go.data_ptr(), gm.data_ptr(),
+                                             gw.data_ptr(), gb.data_ptr(),
                                              ws.data_ptr(), nbytes), "c2m_dcn_v2_backward_f32")
     return gi, go, gm, gw, gb
 

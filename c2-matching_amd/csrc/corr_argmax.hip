@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       // (3) (row_0 + row_1) + row_2 (oracle order); branch-free update of the running (max, lowest index)
       float sum = h0 + h1;
       sum = sum + h2;
-      const float v = has_inv ? sum * scale : sum;
+      const float v = sum * scale;   // scale stays 1.0f without is_norm: exact, and one select fewer per candidate
       const bool take = cand_ok & ((v > best[it]) | ((v == best[it]) & (n < bidx[it])));
       best[it] = take ? v : best[it];
       bidx[it] = take ? n : bidx[it];

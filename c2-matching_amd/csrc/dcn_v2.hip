@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(256) dcn_bwd_data_kernel(const float* __restri
                                                             const float* __restrict__ gout, Geom g,
                                                             float* __restrict__ gin, float* __restrict__ goff,
                                                             float* __restrict__ gmsk) {
+  const bool want_gin = gin != nullptr;  // grad_input is optional: in C2-Matching the warped ref feature never needs it
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = tid >> 6;
   const int b = blockIdx.y;
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(256) dcn_bwd_data_kernel(const float* __restri
   const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
   const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
   const float* go_b = gout + (size_t)b * g.Co * HWo;
-  float* gin_b = gin + (size_t)b * g.C * HW;
+  float* gin_b = want_gin ? gin + (size_t)b * g.C * HW : nullptr;
   float* goff_b = goff + (size_t)b * g.dg * 2 * g.T * HWo;
   float* gmsk_b = gmsk + (size_t)b * g.dg * g.T * HWo;
 
@@ -514,11 +515,13 @@ __global__ void __launch_bounds__(256) dcn_bwd_data_kernel(const float* __restri
           oh += wh * top;   // val += weight * dCol * mask (:317)
           ow += ww * top;
           // col2im scatter (:197-254): the four bilinear corners inside the image
-          float* gi = gin_b + (size_t)c * HW;
-          if (tp.c1 != 0.0f) atomicAdd(gi + tp.a1, tp.w1 * top);
-          if (tp.c2 != 0.0f) atomicAdd(gi + tp.a2, tp.w2 * top);
-          if (tp.c3 != 0.0f) atomicAdd(gi + tp.a3, tp.w3 * top);
-          if (tp.c4 != 0.0f) atomicAdd(gi + tp.a4, tp.w4 * top);
+          if (want_gin) {
+            float* gi = gin_b + (size_t)c * HW;
+            if (tp.c1 != 0.0f) atomicAdd(gi + tp.a1, tp.w1 * top);
+            if (tp.c2 != 0.0f) atomicAdd(gi + tp.a2, tp.w2 * top);
+            if (tp.c3 != 0.0f) atomicAdd(gi + tp.a3, tp.w3 * top);
+            if (tp.c4 != 0.0f) atomicAdd(gi + tp.a4, tp.w4 * top);
+          }
         }
         if (tp.inside) {
           atomicAdd(gmsk_b + (size_t)gt * HWo + pc, mval);
@@ -881,9 +884,8 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
                                        int dw, int dg, float* grad_input, float* grad_offset, float* grad_mask,
                                        float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes) {
   (void)bias;
-  if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask || !grad_weight ||
-      !grad_bias)
-    return C2M_ERR_INVALID_ARG;
+  if (!input || !weight || !offset || !mask || !grad_output || !grad_offset || !grad_mask || !grad_weight || !grad_bias)
+    return C2M_ERR_INVALID_ARG;  // grad_input may be NULL: the scatter into the input gradient is then skipped
   Geom g;
   int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg);
   if (rc != C2M_OK) return rc;
@@ -895,7 +897,7 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   float* wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.wb);
   const int HW = H * W, HWo = g.Ho * g.Wo;
 
-  hipError_t e = hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * C * HW, st);
+  hipError_t e = grad_input ? hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * C * HW, st) : hipSuccess;
   if (e == hipSuccess) e = hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * dg * 2 * g.T * HWo, st);
   if (e == hipSuccess) e = hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * dg * g.T * HWo, st);
   if (e == hipSuccess) e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)Co * C * g.T, st);

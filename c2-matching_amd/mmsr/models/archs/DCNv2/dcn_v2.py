@@ -43,7 +43,8 @@ class _DCNv2(Function):
         (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
         g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(input, weight, bias, offset, mask,
                                                                  grad_output.contiguous(), kh, kw, sh, sw, ph, pw,
-                                                                 dh, dw, dg)
+                                                                 dh, dw, dg,
+                                                                 need_input_grad=ctx.needs_input_grad[0])
         return g_in, g_off, g_mask, g_w, g_b, None, None, None, None
 
 

@@ -103,7 +103,8 @@ int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float*
 
 size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                                            int pw, int dh, int dw, int dg);
-/* All five gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255). */
+/* All gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255).  grad_input may be NULL:
+ * the col2im scatter is then skipped (C2-Matching warps frozen VGG features of the Ref image: that gradient is never used). */
 int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
                             const float* offset, const float* mask, const float* grad_output, int B, int C, int H,
                             int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,

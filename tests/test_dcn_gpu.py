@@ -93,6 +93,19 @@ def test_backward_is_overwriting_not_accumulating(env, dev):
         assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
 
 
+def test_backward_without_input_grad(env, dev):
+    """grad_input is optional at the C-ABI (NULL pointer): the other four gradients must not change."""
+    ops, _, synth = env
+    B, C, H, W, Co, dg = 2, 64, 11, 13, 64, 8
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, 3, 3, (1, 1), (1, 1), (1, 1), dg, 520)
+    args = [_t(a, dev) for a in (x, w, b, off, msk)] + [_t(synth.gaussish((B, Co, H, W), 521), dev)]
+    full = ops.dcn_v2_backward(*args, 1, 1, 1, dg)
+    part = ops.dcn_v2_backward(*args, 1, 1, 1, dg, need_input_grad=False)
+    assert part[0] is None
+    for a, b_ in zip(full[1:], part[1:]):
+        assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
 def test_fuse_offsets_matches_reference_formula(env, dev):
     """dcn_v2.py:229-245 written with the reference's own tensor ops."""
     ops, _, synth = env
