@@ -32,6 +32,22 @@ struct ProfileScope {
   hipStream_t st;
 };
 
+// Raise a kernel's dynamic-LDS limit once per (kernel instantiation, device): the attribute is per device, and
+// nn.DataParallel drives several GPUs from one process.  `done` is a per-instantiation bitmask of devices already set
+// (a race only repeats the idempotent call).
+inline int ensure_dynamic_lds(const void* fn, size_t bytes, unsigned long long& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess && dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return C2M_OK;
+  if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    set_last_error(e);
+    return C2M_ERR_LAUNCH;
+  }
+  if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  return C2M_OK;
+}
+
 inline hipStream_t as_stream(c2m_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

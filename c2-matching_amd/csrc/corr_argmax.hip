@@ -435,13 +435,8 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
   using namespace c2m::corr;
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB + 2 * C * WT);
-  static bool attr_set = false;  // idempotent; a race only repeats the call
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_argmax_mfma_kernel<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_argmax_mfma_kernel<C>), lds, lds_set)) return rc;
   dim3 grid(B * tiles_y * tiles_x);
   ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
   hipLaunchKernelGGL(corr_argmax_mfma_kernel<C>, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y,

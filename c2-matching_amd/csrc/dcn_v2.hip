@@ -733,13 +733,10 @@ int launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const flo
                     const float* msk, const Geom& g, float* out) {
   const int HWo = g.Ho * g.Wo;
   const size_t lds = sizeof(float) * 2 * (size_t)GC * CPG * MT * 32;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;
+  if (lds > 48 * 1024)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC>), lds, lds_set))
+      return rc;
   dim3 grid(ceil_div(HWo, 4 * NT * 32), g.B, g.CoPad / (MT * 32));
   hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
   return C2M_OK;
@@ -847,13 +844,9 @@ template <int MT>
 int launch_bwd_weight(hipStream_t st, dim3 grid, const float* in, const float* off, const float* msk, const float* go,
                       const Geom& g, int chunks_per_b, int nsplit, float* gw) {
   const size_t lds = sizeof(float) * (size_t)(MT * 32 + 32) * dcn::LDP;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn::dcn_bwd_weight_kernel<MT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;
+  if (lds > 48 * 1024)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_bwd_weight_kernel<MT>), lds, lds_set)) return rc;
   hipLaunchKernelGGL((dcn::dcn_bwd_weight_kernel<MT>), grid, dim3(256), lds, st, in, off, msk, go, g, chunks_per_b, nsplit, gw);
   return C2M_OK;
 }
