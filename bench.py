@@ -53,7 +53,7 @@ def corr_step(ops, fin, fref, h):
 def corr_executed_flops(B, C, h):
     """MFMA flops the sweep actually issues (tiles incl. halo / quantisation), per launch."""
     tiles = ((h - 2 + 13) // 14) ** 2
-    steps = ((h - 2 + 29) // 30) * h
+    steps = ((h - 2 + 27) // 28) * h
     return B * tiles * (steps + 1) * 8 * (C // 2) * (2 * 32 * 32 * 2)
 
 

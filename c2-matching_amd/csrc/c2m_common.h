@@ -68,4 +68,10 @@ __device__ __forceinline__ void glds_b32(const float* gsrc, float* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
+// same, 16 bytes per lane (gfx950 global_load_lds_dwordx4): LDS destination = wave-uniform base + lane * 16
+__device__ __forceinline__ void glds_b128(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 }  // namespace c2m

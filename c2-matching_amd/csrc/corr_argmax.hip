@@ -155,24 +155,25 @@ __global__ void __launch_bounds__(256) corr_argmax_generic_kernel(
 namespace corr {
 constexpr int TQ = 16;            // query tile side, pixels
 constexpr int TPQ = TQ - 2;       // query patches per tile side (14)
-constexpr int NQP = TPQ * TPQ;    // 196 query patches per tile
 constexpr int WT = 32;            // ref x-tile width, pixels (= MFMA N)
-constexpr int WP = WT - 2;        // ref patches per x-tile (30)
+constexpr int WP = 28;            // ref patches per x-tile; a multiple of 4 keeps every tile origin 16-byte aligned
+                                  // for the dwordx4 row DMA (30 of the 32 loaded pixel columns are used)
 constexpr int NWAVE = 8;
 constexpr int NTHR = NWAVE * 64;
 constexpr int QPIX = TQ * TQ;     // 256 query pixels per tile
 constexpr int SLAB = QPIX * WT;   // floats per ring slab
-constexpr int NIT = (NQP + 15) / 16;  // 13 tap-sum rounds: 16 query patches per round (8 waves x 2 half-waves)
+constexpr int NIT = TPQ;          // 14 tap-sum rounds: round `it` = query patch ROW it, half-wave (w, hi) = patch column 2w + hi
 }  // namespace corr
 
-template <int C>
+// DMA16: ref rows are fetched with global_load_lds_dwordx4 (needs Wr % 4 == 0 and a 16-byte aligned ref base); otherwise
+// one dword per lane.
+template <int C, bool DMA16>
 __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const float* __restrict__ fin, const float* __restrict__ fref, int Hq, int Wq, int Hr, int Wr, int tiles_y,
     int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int is_norm, int norm_input,
     int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
   using namespace corr;
   constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
-  constexpr int KPG = (KP + NIT - 1) / NIT;    // k-pairs issued between two tap-sum rounds
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;                          // [3][QPIX][WT]
   float* rbuf = smem + 3 * SLAB;               // [2][C][WT]
@@ -183,7 +184,6 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int qy0 = ty * TPQ, qx0 = tx * TPQ;
   const int Hqp = Hq - 2, Wqp = Wq - 2, Hrp = Hr - 2, Wrp = Wr - 2;
-  (void)Hrp;
 
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,53 +196,66 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
   const bool has_inv = is_norm != 0;
   const float* __restrict__ invb = inv + (size_t)b * Hrp * Wrp;
 
-  // ---- resident A operands: lane (i = l&31, k = l>>5) of k-pair t holds in[2t + k][tile pixel 32w + i] ----
+  // ---- resident A operands.  MFMA row i of wave w is tile pixel (row 2w + ((i>>2)&1), column (i&3) + 4*(i>>3)): with the
+  //      32x32 accumulator layout (lane (hi, j) holds rows (r&3) + 8*(r>>2) + 4*hi, r = 0..15) every lane then owns ONE
+  //      query pixel row (2w + hi) with its 16 pixel columns in registers r = 0..15, so "one pixel to the right" is the
+  //      next register of the same lane.  Lane (i = l&31, k = l>>5) of k-pair t holds in[2t + k][pixel(i)].
   float qreg[KP];
   {
-    const int py = min(qy0 + 2 * w + (j32 >> 4), Hq - 1);
-    const int px = min(qx0 + (j32 & 15), Wq - 1);
+    const int py = min(qy0 + 2 * w + ((j32 >> 2) & 1), Hq - 1);
+    const int px = min(qx0 + (j32 & 3) + 4 * (j32 >> 3), Wq - 1);
     const float* src = fi + (size_t)hi * Hq * Wq + (size_t)py * Wq + px;
 #pragma unroll
     for (int t = 0; t < KP; ++t) qreg[t] = src[(size_t)(2 * t) * Hq * Wq];
   }
 
-  // ---- tap-sum bookkeeping: round `it` handles query patch p = it*16 + w*2 + hi for lane-column rx = j32 ----
-  float best[NIT];
-  int bidx[NIT];
-  int pbase[NIT];  // float index of D[(qy, qx)][rx] inside a slab
+  // ---- running arg-max state.  Lane (w, hi, j32) scores query patch (row it, column qx = 2w + hi) against ref column
+  //      j32 of the current x-tile.  Inside one x-tile a lane meets its candidates in ascending index order, so the
+  //      tile-local state (bt, bi) needs only "strictly greater" (one compare); it is merged into (best, bidx) with the
+  //      full (larger value, then lower index) rule once per x-tile.  Wave 7 repeats column 13 (never stored).
+  float best[NIT], bt[NIT];
+  int bidx[NIT], bi[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     best[it] = -INFINITY;
+    bt[it] = -INFINITY;
     bidx[it] = 0x7fffffff;
-    const int p = it * 16 + w * 2 + hi;
-    const int qy = p / TPQ, qx = p - qy * TPQ;
-    pbase[it] = (qy * TQ + qx) * WT + j32;  // p >= NQP (last round only) reads in-bounds garbage, masked below
+    bi[it] = 0x7fffffff;
   }
+  const int qx = min(2 * w + hi, TPQ - 1);
+  const int lane_off = qx * WT + j32;   // float offset of H[(row 0, qx)][j32] inside a slab
 
   const int nxt = (Wrp + WP - 1) / WP;
   const int S = nxt * Hr;
 
-  // DMA of ref pixel row (xt, y) into rbuf[buf]: wave w copies channels [32w, 32w+32) as 16 x (2 channels x 32 px)
+  // DMA of ref pixel row (xt, y) into rbuf[buf] = [C][32]: wave w copies channels [C/8 * w, C/8 * (w+1))
   auto issue_row = [&](int xt, int y, int buf) {
-    const int x = min(xt * WP + j32, Wr - 1);
-    const float* g = fr + (size_t)(w * (C / NWAVE) + hi) * Hr * Wr + (size_t)y * Wr + x;
     float* d = rbuf + buf * (C * WT) + w * (C / NWAVE) * WT;
+    if constexpr (DMA16) {
+      // one instruction = 8 channels x 32 pixels: lane (cs = l>>3, quad = l&7) moves pixels [4 quad, 4 quad + 4)
+      const int x = min(xt * WP + 4 * (l & 7), Wr - 4);
+      const float* g = fr + (size_t)(w * (C / NWAVE) + (l >> 3)) * Hr * Wr + (size_t)y * Wr + x;
 #pragma unroll
-    for (int m = 0; m < C / NWAVE / 2; ++m) glds_b32(g + (size_t)(2 * m) * Hr * Wr, d + (2 * m) * WT);
+      for (int m = 0; m < C / NWAVE / 8; ++m) glds_b128(g + (size_t)(8 * m) * Hr * Wr, d + (8 * m) * WT);
+    } else {
+      const int x = min(xt * WP + j32, Wr - 1);
+      const float* g = fr + (size_t)(w * (C / NWAVE) + hi) * Hr * Wr + (size_t)y * Wr + x;
+#pragma unroll
+      for (int m = 0; m < C / NWAVE / 2; ++m) glds_b32(g + (size_t)(2 * m) * Hr * Wr, d + (2 * m) * WT);
+    }
   };
 
   issue_row(0, 0, 0);
 
-  // Step s processes ref pixel row y of x-tile xt and parks its D tile in ring slab s % 3.  While its MFMA chain
+  // Step s processes ref pixel row y of x-tile xt and parks its row sums H in ring slab s % 3.  While its MFMA chain
   // runs, the lanes finish the patch row completed by step s-1 (rows of steps s-3, s-2, s-1 = slabs s%3, (s+1)%3,
   // (s+2)%3).  Iteration s == S only drains the last pending patch row (its MFMA result is never read).
   int y = 0, xt = 0;   // row / x-tile of step s
   int sl0 = 0;         // s % 3
-  // pending candidate of the NEXT iteration, prefetched one step ahead so its global load never sits between
-  // a row DMA and that DMA's wait
-  bool cand_ok = false;
+  // candidate of the NEXT iteration, prefetched one step ahead so its global load never sits between a row DMA and
+  // that DMA's wait.  scale = NaN marks "no candidate" (NaN never compares greater).
   int n = 0;
-  float scale_next = 1.0f;
+  float scale_next = __builtin_nanf("");
   for (int s = 0; s <= S; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // (A) row s landed in rbuf[s&1]; slab of step s-1 complete; everybody left step s-1
@@ -259,14 +272,15 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const int ncol_nx = xt * WP + j32;
     const bool cand_nx = (s < S) && (y >= 2) && (j32 < WP) && (ncol_nx < Wrp);
     const int n_nx = (y - 2) * Wrp + ncol_nx;
-    scale_next = 1.0f;
-    if (has_inv && cand_nx) scale_next = invb[n_nx];
+    scale_next = __builtin_nanf("");
+    if (cand_nx) scale_next = has_inv ? invb[n_nx] : 1.0f;
 
     const int sl1 = (sl0 == 2) ? 0 : sl0 + 1;
     const int sl2 = (sl1 == 2) ? 0 : sl1 + 1;
-    const float* r0 = ring + sl0 * SLAB;                 // ref row ry     (tap row i = 0)
-    const float* r1 = ring + sl1 * SLAB + TQ * WT;       // ref row ry + 1 (i = 1: query pixel row + 1)
-    const float* r2 = ring + sl2 * SLAB + 2 * TQ * WT;   // ref row ry + 2 (i = 2)
+    // row sums of tap row i for query patch (row it, column qx) live at a_i[it * TQ * WT]: immediate offsets only
+    const float* a0 = ring + sl0 * SLAB + lane_off;                 // ref row ry     (tap row i = 0)
+    const float* a1 = ring + sl1 * SLAB + TQ * WT + lane_off;       // ref row ry + 1 (i = 1: query pixel row + 1)
+    const float* a2 = ring + sl2 * SLAB + 2 * TQ * WT + lane_off;   // ref row ry + 2 (i = 2)
 
     const float* bsrc = rbuf + (s & 1) * (C * WT) + l;  // B operand of k-pair t: rbuf[2t + hi][j32] = bsrc[t * 64]
     f32x16 acc;
@@ -275,74 +289,60 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      // (1) issue the three row-sum reads of round `it`; they are consumed only after this round's MFMA group, so
-      //     their LDS latency is covered by ~KPG*64 cycles of matrix work
-      const int pb = pbase[it];
-      const float h0 = r0[pb], h1 = r1[pb], h2 = r2[pb];
+      // (1) issue the three row-sum reads of round `it`; they are consumed only after this round's MFMA group
+      const float h0 = a0[it * TQ * WT], h1 = a1[it * TQ * WT], h2 = a2[it * TQ * WT];
       __builtin_amdgcn_sched_barrier(0);
-      // (2) MFMA group: k-pairs [it*KPG, (it+1)*KPG)
+      // (2) MFMA group: k-pairs [it*KP/NIT, (it+1)*KP/NIT)
 #pragma unroll
-      for (int t = it * KPG; t < (it + 1) * KPG && t < KP; ++t)
+      for (int t = it * KP / NIT; t < (it + 1) * KP / NIT; ++t)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      // (3) (row_0 + row_1) + row_2 (oracle order); branch-free update of the running (max, lowest index)
+      // (3) (row_0 + row_1) + row_2 (oracle order); strict compare against the tile-local state
       float sum = h0 + h1;
       sum = sum + h2;
-      const float v = sum * scale;   // scale stays 1.0f without is_norm: exact, and one select fewer per candidate
-      const bool take = cand_ok & ((v > best[it]) | ((v == best[it]) & (n < bidx[it])));
-      best[it] = take ? v : best[it];
-      bidx[it] = take ? n : bidx[it];
+      const float v = sum * scale;   // scale is exactly 1.0f without is_norm, NaN without a candidate
+      const bool take = v > bt[it];
+      bt[it] = take ? v : bt[it];
+      bi[it] = take ? n : bi[it];
     }
-
-    cand_ok = cand_nx;
     n = n_nx;
+
+    if (y == 0 && s > 0) {
+      // the rounds above finished the last patch row of an x-tile: merge its state (larger value, then lower index).
+      // The empty volatile asm keeps this a real (wave-uniform) branch: if-converted it would run on every step.
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const bool take = (bt[it] > best[it]) | ((bt[it] == best[it]) & (bi[it] < bidx[it]));
+        best[it] = take ? bt[it] : best[it];
+        bidx[it] = take ? bi[it] : bidx[it];
+        bt[it] = -INFINITY;
+        bi[it] = 0x7fffffff;
+      }
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
 
-    // Row sums of the 3 taps of a patch row, formed in registers: lane (hi, j) holds rows i(r) = (r&3) + 8*(r>>2) + 4*hi
-    // of column j.  nxt(V)[r] = V at (row i+1, column j+1): the next register of the same lane shifted by one lane
-    // (DPP wave_shl:1), except for r&3 == 3 where row i+1 lives in the other half-wave (v_permlane32_swap).
-    //   t[r] = D[r] + nxt(D)[r]      = D[i][j] + D[i+1][j+1]
-    //   H[r] = D[r] + nxt(t)[r]      = D[i][j] + (D[i+1][j+1] + D[i+2][j+2])
-    // Elements whose taps would leave the 16-pixel tile row or the 32-column x-tile are never used as patch origins.
+    // Row sums of the 3 taps of a patch row, formed in registers.  Lane (hi, j) holds D[pixel (2w+hi, r)][ref column j]
+    // in acc[r]; V at (pixel column + 1, ref column + 1) is the next register shifted by one lane (DPP wave_shl:1):
+    //   t[r] = D[r] + shl(D[r+1])      = D[px][j] + D[px+1][j+1]
+    //   H[r] = D[r] + shl(t[r+1])      = D[px][j] + (D[px+1][j+1] + D[px+2][j+2])          (oracle tap order)
+    // Only patch origins px < 14, j < 28 are ever read back.
     auto shl1 = [](float x) __attribute__((always_inline)) {
       return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
     };
     {
-      float dv[16], nx[16], tt[16], hh[16];
+      float dv[16], tt[16], hh[TPQ];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dv[r] = acc[r];
-      // pass 1: t = D + nxt(D)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // row 4 + 8g + 4hi lives in the other half-wave: hi = 0 wants the partner's V[4g], hi = 1 the partner's V[4(g+1)]
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, dv[4 * g]),
-                                                         __builtin_bit_cast(unsigned, dv[g < 3 ? 4 * g + 4 : 4 * g]),
-                                                         false, false);   // sw[0] = (a.lo, b.lo), sw[1] = (a.hi, b.hi)
-        nx[4 * g + 0] = dv[4 * g + 1];
-        nx[4 * g + 1] = dv[4 * g + 2];
-        nx[4 * g + 2] = dv[4 * g + 3];
-        nx[4 * g + 3] = __builtin_bit_cast(float, hi ? sw[0] : sw[1]);
-      }
+      for (int r = 1; r < 15; ++r) tt[r] = dv[r] + shl1(dv[r + 1]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tt[r] = dv[r] + shl1(nx[r]);
-      // pass 2: H = D + nxt(t)
+      for (int r = 0; r < TPQ; ++r) hh[r] = dv[r] + shl1(tt[r + 1]);
+      float* dst = ring + sl0 * SLAB + (2 * w + hi) * TQ * WT + j32;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tt[4 * g]),
-                                                         __builtin_bit_cast(unsigned, tt[g < 3 ? 4 * g + 4 : 4 * g]),
-                                                         false, false);
-        nx[4 * g + 0] = tt[4 * g + 1];
-        nx[4 * g + 1] = tt[4 * g + 2];
-        nx[4 * g + 2] = tt[4 * g + 3];
-        nx[4 * g + 3] = __builtin_bit_cast(float, hi ? sw[0] : sw[1]);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hh[r] = dv[r] + shl1(nx[r]);
-      float* dst = ring + sl0 * SLAB + (32 * w + 4 * hi) * WT + j32;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * WT] = hh[r];
+      for (int r = 0; r < TPQ; ++r) dst[r * WT] = hh[r];
     }
 
     y = yn;
@@ -363,10 +363,8 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       v = take ? v2 : v;
       i = take ? i2 : i;
     }
-    const int p = it * 16 + w * 2 + hi;
-    const int qy = p / TPQ, qx = p - qy * TPQ;
-    const int gy = qy0 + qy, gx = qx0 + qx;
-    if (j32 == 0 && p < NQP && gy < Hqp && gx < Wqp) {
+    const int gy = qy0 + it, gx = qx0 + 2 * w + hi;
+    if (j32 == 0 && w < NWAVE - 1 && gy < Hqp && gx < Wqp) {
       const size_t o = (size_t)b * Hqp * Wqp + (size_t)gy * Wqp + gx;
       if (norm_input) v = v / qden[o];
       max_idx[o] = (int64_t)i;
@@ -435,12 +433,14 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
   using namespace c2m::corr;
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB + 2 * C * WT);
-  static unsigned long long lds_set = 0;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&corr_argmax_mfma_kernel<C>), lds, lds_set)) return rc;
+  static unsigned long long lds_set[2] = {0, 0};
+  const bool dma16 = (Wr % 4 == 0) && (reinterpret_cast<uintptr_t>(fref) % 16 == 0);
+  auto kern = dma16 ? &corr_argmax_mfma_kernel<C, true> : &corr_argmax_mfma_kernel<C, false>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set[dma16])) return rc;
   dim3 grid(B * tiles_y * tiles_x);
   ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
-  hipLaunchKernelGGL(corr_argmax_mfma_kernel<C>, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y,
-                     tiles_x, inv ? inv : fin, qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, max_idx, max_val);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y, tiles_x, inv ? inv : fin,
+                     qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, max_idx, max_val);
   return check_launch();
 }
 }  // namespace

@@ -1,10 +1,10 @@
 // Micro-benchmark: does v_mfma_f32_32x32x2_f32 share execution resources with ordinary f32 VALU work on gfx950?
 // 8 waves per workgroup (2 per SIMD), 1 workgroup per CU (LDS-limited like the correlation kernel).
 //   mode 0: every wave runs a dependent MFMA chain
-//   mode 1: even waves MFMA chain, odd waves idle (exit)                    -> one MFMA wave per SIMD
-//   mode 2: even waves MFMA chain, odd waves run an f32 VALU fma loop       -> MFMA + VALU wave per SIMD
-//   mode 3: even waves MFMA chain, odd waves run an LDS read loop           -> MFMA + LDS wave per SIMD
-//   mode 4: odd waves only the VALU loop (for its standalone time)
+//   mode 1: waves 0..3 MFMA chain, waves 4..7 idle (exit)                  -> one MFMA wave per SIMD
+//   mode 2: waves 0..3 MFMA chain, waves 4..7 run an f32 VALU fma loop     -> MFMA + VALU wave per SIMD
+//   mode 3: waves 0..3 MFMA chain, waves 4..7 run an LDS read loop         -> MFMA + LDS wave per SIMD
+//   mode 4: waves 4..7 only the VALU loop (for its standalone time)
 // Reports ms and the MFMA TFLOP/s of the MFMA waves.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(768, 3) k(float* out, int iters, int valu_iter
   __syncthreads();
   // modes 5/6/7: waves 0..7 run the MFMA chain (2 per SIMD = full matrix rate), waves 8..11 run VALU / LDS / nothing
   if (MODE <= 4 && w >= 8) return;
-  const bool mf = (MODE == 0) || (MODE >= 5 ? w < 8 : ((w & 1) == 0));
+  const bool mf = (MODE == 0) || (MODE >= 5 ? w < 8 : (w < 4));   // waves map to SIMD w % 4
   if (mf && MODE != 4) {
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -47,6 +47,37 @@ __global__ void __launch_bounds__(768, 3) k(float* out, int iters, int valu_iter
   }
 }
 
+template <int NCH>
+__global__ void __launch_bounds__(256, 1) kchain(float* out, int iters) {   // 4 waves per workgroup = 1 per SIMD
+  const int l = threadIdx.x & 63;
+  f32x16 acc[NCH];
+  for (int c = 0; c < NCH; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  float a = 1.0f + l, b = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int t = 0; t < 32 / NCH; ++t)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int c = 0; c < NCH; ++c) s += acc[c][0];
+  if (s == 12345.f) out[threadIdx.x] = s;
+}
+
+template <int NCH>
+float run_chain(float* d, int iters) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(kchain<NCH>, dim3(256), dim3(256), 0, 0, d, 16);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL(kchain<NCH>, dim3(256), dim3(256), 0, 0, d, iters);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+
 template <int MODE>
 float run(float* d, int iters, int vi) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -68,8 +99,14 @@ int main() {
   const double fl_per_wave = (double)iters * 32 * 4096;
   float t0 = run<0>(d, iters, 0), t1 = run<1>(d, iters, 0);
   // VALU loop sized to last about as long as the MFMA chain: 32*4 fma per iter, 2 cycles each -> 256 cyc/iter vs 2048 cyc/iter MFMA
-  float t4 = run<4>(d, iters, iters * 8);
-  float t2 = run<2>(d, iters, iters * 8), t3 = run<3>(d, iters, iters * 8);
+  float t4 = run<4>(d, iters, iters * 2);
+  float t2 = run<2>(d, iters, iters * 2), t3 = run<3>(d, iters, iters * 2);
+  {
+    float c1 = run_chain<1>(d, iters), c2 = run_chain<2>(d, iters), c4 = run_chain<4>(d, iters);
+    const double fl = 256.0 * 4 * iters * 32 * 4096;
+    printf("{\"one_wave_per_simd_1chain_tflops\": %.1f, \"2chains_tflops\": %.1f, \"4chains_tflops\": %.1f}\n",
+           fl / (c1 * 1e-3) / 1e12, fl / (c2 * 1e-3) / 1e12, fl / (c4 * 1e-3) / 1e12);
+  }
   float t7 = run<7>(d, iters, 0);
   float t5a = run<5>(d, iters, iters * 2), t5b = run<5>(d, iters, iters * 4), t6a = run<6>(d, iters, iters / 2), t6b = run<6>(d, iters, iters);
   printf("{\"mode7_8mfma_4idle_ms\": %.3f, \"mode5_8mfma_4valu_quarter_ms\": %.3f, \"mode5_8mfma_4valu_half_ms\": %.3f, "
