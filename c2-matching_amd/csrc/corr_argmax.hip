@@ -287,23 +287,38 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
+    // Software pipeline over the 14 rounds.  Round `it`: the first MFMA of group `it` consumes operands fetched a whole
+    // round earlier (the compiler's s_waitcnt lgkmcnt(0) in front of it is then free); only after it are the B operands
+    // of group it+1 and the three row sums of round it+1 requested, to land under the remaining MFMAs of the group.
+    constexpr int KPG = (KP + NIT - 1) / NIT;
+    float bq[2][KPG], hq[2][3];
+#pragma unroll
+    for (int t = 0; t < KP / NIT; ++t) bq[0][t] = bsrc[t * 64];
+    hq[0][0] = a0[0]; hq[0][1] = a1[0]; hq[0][2] = a2[0];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      // (1) issue the three row-sum reads of round `it`; they are consumed only after this round's MFMA group
-      const float h0 = a0[it * TQ * WT], h1 = a1[it * TQ * WT], h2 = a2[it * TQ * WT];
+      const int t0 = it * KP / NIT, t1 = (it + 1) * KP / NIT, t2 = (it + 2) * KP / NIT;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t0], bq[it & 1][0], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      // (2) MFMA group: k-pairs [it*KP/NIT, (it+1)*KP/NIT)
+      if (it + 1 < NIT) {
 #pragma unroll
-      for (int t = it * KP / NIT; t < (it + 1) * KP / NIT; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bsrc[t * 64], acc, 0, 0, 0);
+        for (int t = t1; t < t2; ++t) bq[(it + 1) & 1][t - t1] = bsrc[t * 64];
+        hq[(it + 1) & 1][0] = a0[(it + 1) * TQ * WT];
+        hq[(it + 1) & 1][1] = a1[(it + 1) * TQ * WT];
+        hq[(it + 1) & 1][2] = a2[(it + 1) * TQ * WT];
+      }
       __builtin_amdgcn_sched_barrier(0);
-      // (3) (row_0 + row_1) + row_2 (oracle order); strict compare against the tile-local state
-      float sum = h0 + h1;
-      sum = sum + h2;
+#pragma unroll
+      for (int t = t0 + 1; t < t1; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qreg[t], bq[it & 1][t - t0], acc, 0, 0, 0);
+      // (row_0 + row_1) + row_2 (oracle order); strict compare against the tile-local state
+      float sum = hq[it & 1][0] + hq[it & 1][1];
+      sum = sum + hq[it & 1][2];
       const float v = sum * scale;   // scale is exactly 1.0f without is_norm, NaN without a candidate
       const bool take = v > bt[it];
       bt[it] = take ? v : bt[it];
       bi[it] = take ? n : bi[it];
+      __builtin_amdgcn_sched_barrier(0);
     }
     n = n_nx;
 
