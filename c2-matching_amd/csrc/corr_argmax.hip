@@ -35,6 +35,7 @@ namespace c2m {
 // ------------------------------------------------------------------------------------------------------------------
 
 // F.normalize over channels (corres_generation_arch.py:56-58): thread = pixel, coalesced over pixels per channel.
+// Generic version: two passes over the pixel's channel column (the second read mostly misses L2 at 160x160x256).
 __global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __restrict__ x, int C, int HW,
                                                                  float* __restrict__ out) {
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -49,6 +50,28 @@ __global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __r
   const float nrm = sqrtf(ss);
   const float den = nrm > 1e-12f ? nrm : 1e-12f;
   for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = xb[(size_t)c * HW] / den;
+}
+
+// Same arithmetic (one fmaf chain, c ascending), but the pixel's whole channel column stays in registers between the
+// two passes: one HBM read + one write per element, C independent loads in flight per lane.  One wave per SIMD
+// (C + a few VGPRs), which is plenty for a pure streaming kernel.
+template <int C>
+__global__ void __launch_bounds__(256, 1) feature_normalize_reg_kernel(const float* __restrict__ x, int HW,
+                                                                        float* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float* xb = x + (size_t)blockIdx.y * C * HW + p;
+  float* ob = out + (size_t)blockIdx.y * C * HW + p;
+  float v[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) v[c] = xb[(size_t)c * HW];
+  float ss = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) ss = fmaf(v[c], v[c], ss);
+  const float nrm = sqrtf(ss);
+  const float den = nrm > 1e-12f ? nrm : 1e-12f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = v[c] / den;
 }
 
 // per-pixel sum of squares over channels (canonical fmaf chain, c ascending)
@@ -422,7 +445,11 @@ using namespace c2m;
 extern "C" int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out) {
   if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return C2M_ERR_INVALID_ARG;
   dim3 grid(ceil_div(HW, 256), B);
-  hipLaunchKernelGGL(feature_normalize_kernel, grid, dim3(256), 0, as_stream(stream), x, C, HW, out);
+  hipStream_t st = as_stream(stream);
+  if (C == 256) hipLaunchKernelGGL(feature_normalize_reg_kernel<256>, grid, dim3(256), 0, st, x, HW, out);
+  else if (C == 128) hipLaunchKernelGGL(feature_normalize_reg_kernel<128>, grid, dim3(256), 0, st, x, HW, out);
+  else if (C == 64) hipLaunchKernelGGL(feature_normalize_reg_kernel<64>, grid, dim3(256), 0, st, x, HW, out);
+  else hipLaunchKernelGGL(feature_normalize_kernel, grid, dim3(256), 0, st, x, C, HW, out);
   return check_launch();
 }
 
