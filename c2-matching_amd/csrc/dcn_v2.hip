@@ -219,23 +219,30 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_mfma_kernel(const float* __res
 // or textured data, incoherent between neighbouring pixels: in NCHW every (corner, channel) of a gather is its own
 // cache line; channels-last makes one corner = one contiguous C/dg-vector and lets all groups share the pixel's line.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW,
+// The copy carries a zero border: 1 pixel on the top/left, 2 on the bottom/right ((H+3) x (W+3) pixels).  A sample
+// position clamped to [-1, H] x [-1, W] then always has its four corners inside the buffer and every corner the reference
+// treats as "outside" (dcn_v2_im2col_cuda.cu:36-47, 180) reads 0 -- no per-corner validity logic in the hot loop.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int H, int W,
                                                             float* __restrict__ out) {
   __shared__ float tile[32][33];
+  const int Wp = W + 3, PP = (H + 3) * Wp, HW = H * W;
   const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const float* ib = in + (size_t)b * C * HW;
-  float* ob = out + (size_t)b * C * HW;
+  float* ob = out + (size_t)b * C * PP;
+  const int pp = p0 + tx;
+  const int yy = pp / Wp - 1, xx = pp - (yy + 1) * Wp - 1;
+  const bool inside = pp < PP && yy >= 0 && yy < H && xx >= 0 && xx < W;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int c = c0 + ty + 8 * r, p = p0 + tx;
-    tile[ty + 8 * r][tx] = (c < C && p < HW) ? ib[(size_t)c * HW + p] : 0.0f;
+    const int c = c0 + ty + 8 * r;
+    tile[ty + 8 * r][tx] = (c < C && inside) ? ib[(size_t)c * HW + yy * W + xx] : 0.0f;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int p = p0 + ty + 8 * r, c = c0 + tx;
-    if (c < C && p < HW) ob[(size_t)p * C + c] = tile[tx][ty + 8 * r];
+    if (c < C && p < PP) ob[(size_t)p * C + c] = tile[tx][ty + 8 * r];
   }
 }
 
@@ -265,22 +272,25 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y, ob = blockIdx.z;
-  const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+  const int HWo = g.Ho * g.Wo;
   const int p0 = (blockIdx.x * 4 + wv) * (NT * 32);  // may lie beyond HWo for the last waves: they still hit the barriers
-  const float* in_b = inl + (size_t)b * g.C * HW;
+  const int Wp = g.W + 3;                                          // zero-bordered staging copy (nchw_to_nhwc_kernel)
+  const float* in_b = inl + (size_t)b * g.C * (g.H + 3) * Wp;
   const int dg_real = SPLITG ? 2 * g.dg : g.dg;
   const float* off_b = offset + (size_t)b * dg_real * 2 * g.T * HWo;
   const float* msk_b = mask + (size_t)b * dg_real * g.T * HWo;
 
-  int py[NT], px[NT], pc[NT];
+  int pc[NT];
+  float fy[NT], fx[NT];   // sample position of tap (0, 0) without offset
   bool pok[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int p = p0 + nt * 32 + j;
     pok[nt] = p < HWo;
-    pc[nt] = min(p, HWo - 1);
-    py[nt] = pc[nt] / g.Wo;
-    px[nt] = pc[nt] - py[nt] * g.Wo;
+    pc[nt] = min(p, HWo - 1);   // lanes past the end recompute the last pixel and simply do not store
+    const int py = pc[nt] / g.Wo, px = pc[nt] - py * g.Wo;
+    fy[nt] = (float)(py * g.sh - g.ph);
+    fx[nt] = (float)(px * g.sw - g.pw);
   }
 
   f32x16 acc[MT][NT];
@@ -315,26 +325,21 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
     for (int nt = 0; nt < NT; ++nt) r[nt] = load_raw_tap(g, off_b, msk_b, SPLITG ? 2 * grp + hi : grp, tap, pc[nt]);
   };
   struct Gath { f32x4 v1[NQ], v2[NQ], v3[NQ], v4[NQ]; };
-  // blend weights of one step: corner validity (:36-47, :180) and the modulation mask (:189) folded into the four
-  // bilinear weights once per (pixel, group, tap) instead of per channel
+  // Sampling state of one (pixel, group, tap): element offset of the top-left corner in the bordered copy and the four
+  // bilinear weights with the modulation mask (:189) folded in.  Clamping the position to [-1, H] x [-1, W] puts every
+  // "outside" corner (:36-47, :180) on the zero border, so no validity flags exist.
+  struct Samp { unsigned o1; float w1, w2, w3, w4; };
   struct Wts { float w1, w2, w3, w4; };
-  auto fold = [&](const Tap& t) {
-    Wts o;
-    o.w1 = t.c1 != 0.0f ? t.w1 * t.mk : 0.0f;
-    o.w2 = t.c2 != 0.0f ? t.w2 * t.mk : 0.0f;
-    o.w3 = t.c3 != 0.0f ? t.w3 * t.mk : 0.0f;
-    o.w4 = t.c4 != 0.0f ? t.w4 * t.mk : 0.0f;
-    return o;
-  };
+  const float Hf = (float)g.H, Wf = (float)g.W;
   const unsigned lane_ch = hi * HALF;   // this lane's half-run inside its group
-  auto gather = [&](int grp, const Tap (&tp)[NT], Gath (&gv)[NT]) {
+  const int obase = (Wp + 1) * g.C + (int)lane_ch;   // bordered pixel (1, 1) = image pixel (0, 0)
+  auto gather = [&](int grp, const Samp (&sp)[NT], Gath (&gv)[NT]) {
     const float* gb = in_b + grp * CPG;   // wave-uniform base; per-lane part stays a 32-bit element offset
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const unsigned o1 = (unsigned)tp[nt].a1 * (unsigned)g.C + lane_ch, o2 = (unsigned)tp[nt].a2 * (unsigned)g.C + lane_ch;
-      const unsigned o3 = (unsigned)tp[nt].a3 * (unsigned)g.C + lane_ch, o4 = (unsigned)tp[nt].a4 * (unsigned)g.C + lane_ch;
+      const unsigned o1 = sp[nt].o1, o2 = o1 + (unsigned)g.C, o3 = o1 + (unsigned)(Wp * g.C), o4 = o3 + (unsigned)g.C;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {  // clamped addresses are always readable; validity is applied through the weights
+      for (int q = 0; q < NQ; ++q) {
         gv[nt].v1[q] = *reinterpret_cast<const f32x4*>(gb + o1 + 4 * q);
         gv[nt].v2[q] = *reinterpret_cast<const f32x4*>(gb + o2 + 4 * q);
         gv[nt].v3[q] = *reinterpret_cast<const f32x4*>(gb + o3 + 4 * q);
@@ -343,85 +348,116 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
     }
   };
 
-  // (tap, group) of steps gs, gs+1, gs+2 are tracked with counters (no integer divisions in the loop)
+  // (tap, group) of steps gs+1 and gs+2 are tracked with wave-uniform counters (no divisions, no branches: the step loop
+  // below must stay one basic block so that the compiler can wait with exact vmcnt counts).  The counters saturate at
+  // the last (tap, group): the two look-ahead stages past the end re-sample it (valid addresses, results unused).
   struct Pos { int tap, grp, ti, tj; };
   auto advance = [&](Pos& p) {
-    if (++p.grp == g.dg) {
-      p.grp = 0;
-      ++p.tap;
-      if (++p.tj == g.kw) { p.tj = 0; ++p.ti; }
+    const bool last = (p.tap == g.T - 1) & (p.grp == g.dg - 1);
+    const bool wrap = p.grp == g.dg - 1;           // next step starts a new tap
+    const bool roww = wrap & (p.tj == g.kw - 1);   // ... in a new kernel row
+    Pos n;
+    n.grp = wrap ? 0 : p.grp + 1;
+    n.tap = wrap ? p.tap + 1 : p.tap;
+    n.tj = roww ? 0 : (wrap ? p.tj + 1 : p.tj);
+    n.ti = roww ? p.ti + 1 : p.ti;
+    p.grp = last ? p.grp : n.grp;
+    p.tap = last ? p.tap : n.tap;
+    p.tj = last ? p.tj : n.tj;
+    p.ti = last ? p.ti : n.ti;
+  };
+  auto state = [&](const RawTap (&r)[NT], const Pos& p, Samp (&sp)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float ah = __builtin_amdgcn_fmed3f((fy[nt] + (float)(p.ti * g.dh)) + r[nt].oh, -1.0f, Hf);
+      const float aw = __builtin_amdgcn_fmed3f((fx[nt] + (float)(p.tj * g.dw)) + r[nt].ow, -1.0f, Wf);
+      const float fh = floorf(ah), fw = floorf(aw);
+      const float lh = ah - fh, lw = aw - fw;
+      const float hw = 1.0f - lw;
+      const float mh = (1.0f - lh) * r[nt].mk, ml = lh * r[nt].mk;
+      sp[nt].w1 = mh * hw; sp[nt].w2 = mh * lw; sp[nt].w3 = ml * hw; sp[nt].w4 = ml * lw;
+      sp[nt].o1 = (unsigned)(((int)fh * Wp + (int)fw) * g.C + obase);
     }
   };
-  auto state = [&](const RawTap (&r)[NT], const Pos& p, Tap (&tp)[NT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) tp[nt] = tap_from_raw_ij(g, r[nt], p.ti, p.tj, py[nt], px[nt], pok[nt]);
-  };
-  // one pipeline step: issue (state + gathers) of step gs+1 into (tpB, gvB), raw loads of step gs+2, then blend + MFMAs
-  // of step gs from (wA, gvA).  Called alternately with the two register sets swapped, so nothing is ever copied.
+  // One pipeline step: issue (state + gathers) of step gs+1 into (wB, gvB) and the raw loads of step gs+2, then blend +
+  // MFMAs of step gs from (wA, gvA), whose gathers were issued one step earlier.  Called alternately with the two
+  // register sets swapped, so nothing is ever copied.  Branch-free on purpose (see Pos).
   RawTap raw[NT];
   Pos p1{0, 0, 0, 0}, p2{0, 0, 0, 0};   // positions of steps gs+1 and gs+2
-  auto step = [&](int gs, Wts (&wA)[NT], Gath (&gvA)[NT], Wts (&wB)[NT], Gath (&gvB)[NT]) __attribute__((always_inline)) {
-    const int ci = gs / GC, gi = gs - ci * GC;   // GC is a power of two
-    if (gi == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // chunk ci landed in wl[ci&1]; every wave is done reading wl[(ci+1)&1]
-      if ((ci + 1) * GC < nstep) stage(ci + 1, (ci + 1) & 1);
-    }
-    if (gs + 1 < nstep) {
-      Tap tp[NT];
-      state(raw, p1, tp);
-      gather(p1.grp, tp, gvB);
+  auto step = [&](int ci, int gi, Wts (&wA)[NT], Gath (&gvA)[NT], Wts (&wB)[NT], Gath (&gvB)[NT]) __attribute__((always_inline)) {
+    {
+      Samp sp[NT];
+      state(raw, p1, sp);
+      gather(p1.grp, sp, gvB);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wB[nt] = fold(tp[nt]);
-      if (gs + 2 < nstep) raw_at(p2.tap, p2.grp, raw);
+      for (int nt = 0; nt < NT; ++nt) wB[nt] = Wts{sp[nt].w1, sp[nt].w2, sp[nt].w3, sp[nt].w4};
+      raw_at(p2.tap, p2.grp, raw);
       advance(p1);
       advance(p2);
     }
-    // blend step gs: w1*v1 + w2*v2 + w3*v3 + w4*v4 with mask and validity already inside the weights (fma chain;
-    // differs from the oracle's (w1*v1 + ... ) * mask by rounding only -- DCNv2 parity is tolerance-based)
-    float col[NT][HALF];
+    // keep the scheduler from sinking the look-ahead loads below the MFMAs they are meant to overlap with
+    __builtin_amdgcn_sched_barrier(0);
+    // blend step gs: w1*v1 + w2*v2 + w3*v3 + w4*v4 with the mask already inside the weights (fma chain; differs from the
+    // oracle's (w1*v1 + ... ) * mask by rounding only -- DCNv2 parity is tolerance-based).  Software pipeline over the
+    // k-pairs: the LDS read of the A operands and the blend of the B operand of k-pair t+1 are issued in front of the
+    // MFMAs of k-pair t.
+    auto blend = [&](int t, float (&c)[NT]) __attribute__((always_inline)) {
+      const int q = t >> 2, e = t & 3;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          col[nt][4 * q + e] = fmaf(wA[nt].w4, gvA[nt].v4[q][e], fmaf(wA[nt].w3, gvA[nt].v3[q][e],
-                               fmaf(wA[nt].w2, gvA[nt].v2[q][e], wA[nt].w1 * gvA[nt].v1[q][e])));
-      }
-    }
+      for (int nt = 0; nt < NT; ++nt)
+        c[nt] = fmaf(wA[nt].w4, gvA[nt].v4[q][e], fmaf(wA[nt].w3, gvA[nt].v3[q][e],
+                fmaf(wA[nt].w2, gvA[nt].v2[q][e], wA[nt].w1 * gvA[nt].v1[q][e])));
+    };
     // MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
     const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
+    float aop[2][MT], col[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aop[0][mt] = wrow[mt * 32];
+    blend(0, col[0]);
 #pragma unroll
     for (int t = 0; t < HALF; ++t) {
+      if (t + 1 < HALF) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float a = wrow[(2 * t) * MW + mt * 32];
+        for (int mt = 0; mt < MT; ++mt) aop[(t + 1) & 1][mt] = wrow[(2 * (t + 1)) * MW + mt * 32];
+        blend(t + 1, col[(t + 1) & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, col[nt][t], acc[mt][nt], 0, 0, 0);
-      }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[t & 1][mt], col[t & 1][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   Wts w0[NT], w1s[NT];
   Gath gv0[NT], gv1[NT];
   {
-    Pos p0{0, 0, 0, 0};
-    Tap tp[NT];
+    Pos pz{0, 0, 0, 0};
+    Samp sp[NT];
     raw_at(0, 0, raw);
-    state(raw, p0, tp);
-    gather(0, tp, gv0);
+    state(raw, pz, sp);
+    gather(0, sp, gv0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w0[nt] = fold(tp[nt]);
+    for (int nt = 0; nt < NT; ++nt) w0[nt] = Wts{sp[nt].w1, sp[nt].w2, sp[nt].w3, sp[nt].w4};
     advance(p1);                 // step 1
     advance(p2); advance(p2);    // step 2
-    if (nstep > 1) raw_at(p1.tap, p1.grp, raw);
+    raw_at(p1.tap, p1.grp, raw);
   }
+  static_assert(GC % 2 == 0, "the step pairs (two register sets) must not straddle a weight chunk");
+  const int nchunk = nstep / GC;   // GC divides dg
   stage(0, 0);
-  for (int gs = 0; gs < nstep; gs += 2) {
-    step(gs, w0, gv0, w1s, gv1);
-    if (gs + 1 < nstep) step(gs + 1, w1s, gv1, w0, gv0);
+  for (int ci = 0; ci < nchunk; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk ci landed in wl[ci&1]; every wave is done reading wl[(ci+1)&1]
+    stage(min(ci + 1, nchunk - 1), (ci + 1) & 1);   // (the last iteration re-stages its own chunk into the idle buffer)
+#pragma unroll
+    for (int gi = 0; gi < GC; gi += 2) {
+      step(ci, gi, w0, gv0, w1s, gv1);
+      step(ci, gi + 1, w1s, gv1, w0, gv0);
+    }
   }
 
   float* out_b = out + (size_t)b * g.Co * HWo;
@@ -760,10 +796,8 @@ int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const fl
   if constexpr (FIT >= 4) {
     if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4, SPLITG>(st, inl, wt, bias, off, msk, g, out);
   }
-  if constexpr (FIT >= 2) {
-    if (g.dg % 2 == 0) return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG>(st, inl, wt, bias, off, msk, g, out);
-  }
-  return launch_fwd_nhwc<MT, NT, CPG, 1, SPLITG>(st, inl, wt, bias, off, msk, g, out);
+  static_assert(FIT >= 2, "two groups' weight rows must fit one chunk");
+  return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG>(st, inl, wt, bias, off, msk, g, out);   // use_nhwc() guarantees an even dg
 }
 
 template <int CPG, bool SPLITG>
@@ -782,7 +816,9 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
   }
 }
 
-inline bool use_nhwc(const Geom& g) { return g.CPG == 8 || g.CPG == 16 || g.CPG == 32; }
+// channels-last fast path: 8/16/32 channels per deformable group and an even number of groups (its step pairs and weight
+// chunks cover two groups at a time); everything else takes the NCHW kernel
+inline bool use_nhwc(const Geom& g) { return (g.CPG == 8 || g.CPG == 16 || g.CPG == 32) && g.dg % 2 == 0; }
 
 template <int MT, int NT>
 void launch_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, const float* off, const float* msk,
@@ -797,7 +833,7 @@ extern "C" size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W,
   Geom g;
   if (make_geom(g, B, C, H, W, Co, kh, kw, 1, 1, kh, kw, 1, 1, dg) != C2M_OK) return 0;
   size_t n = align256(sizeof(float) * (size_t)g.KtotPad * copad_fwd(Co));
-  if (use_nhwc(g)) n += align256(sizeof(float) * (size_t)B * C * H * W);  // channels-last staging copy of the input
+  if (use_nhwc(g)) n += align256(sizeof(float) * (size_t)B * C * (H + 3) * (W + 3));  // zero-bordered channels-last copy
   return n;
 }
 
@@ -813,18 +849,18 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
   g.CoPad = copad_fwd(Co);
   const bool nhwc = use_nhwc(g);
   const size_t wbytes = align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
-  const size_t need = wbytes + (nhwc ? align256(sizeof(float) * (size_t)B * C * H * W) : 0);
+  const size_t need = wbytes + (nhwc ? align256(sizeof(float) * (size_t)B * C * (H + 3) * (W + 3)) : 0);
   if (!workspace || workspace_bytes < need) return C2M_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   float* wt = static_cast<float*>(workspace);
   float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
   if (nhwc)
-    hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), B), dim3(256), 0, st, input, C,
-                       H * W, inl);
+    hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
+                       st, input, C, H, W, inl);
   // 8-channel groups are processed as virtual groups of two (see SPLITG): the kernel and the weight re-layout see the
   // virtual grouping, which leaves the K order a plain (tap, group, kk) order over real channels.  (Measured, B=16: large
   // layer 16.4 -> 13.7 ms on random flows, 7.6 -> 7.1 ms on coherent ones; 16-channel groups lose 2-10 %, so they stay.)
-  const bool split = nhwc && g.CPG == 8 && g.dg % 2 == 0;
+  const bool split = nhwc && g.CPG == 8 && g.dg % 4 == 0;   // the virtual grouping must keep an even group count
   Geom gk = g;
   if (split) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
   hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, gk, 0,
