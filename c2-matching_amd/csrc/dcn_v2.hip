@@ -117,7 +117,18 @@ __global__ void __launch_bounds__(256) weight_relayout_kernel(const float* __res
   const int o = e / g.KtotPad, k = e - o * g.KtotPad;
   float v = 0.0f;
   if (o < g.Co && k < g.Ktot) {
-    if (nhwc_order) {
+    if (nhwc_order == 2) {
+      // backward offset/mask kernel: k tile = 32 rows of one tap; row i of the tile is held by half-wave hi = (i>>2)&1 at
+      // accumulator index li = 4*(i>>3) + (i&3), and each lane must own whole (or, for 32-channel groups, half) groups
+      const int kt = k >> 5, i = k & 31, tpt = g.C / 32;
+      const int tap = kt / tpt, gtile = kt - tap * tpt;
+      const int hi = (i >> 2) & 1, li = ((i >> 3) << 2) + (i & 3);
+      int grp, ch;
+      if (g.CPG == 32) { grp = gtile; ch = 16 * hi + li; }
+      else if (g.CPG == 16) { grp = 2 * gtile + hi; ch = li; }
+      else { grp = 4 * gtile + 2 * (li >> 3) + hi; ch = li & 7; }
+      v = w[((size_t)o * g.C + grp * g.CPG + ch) * g.T + tap];
+    } else if (nhwc_order) {
       const int tg = k / g.CPG, kk = k - tg * g.CPG;
       const int tap = tg / g.dg, grp = tg - tap * g.dg;
       const int cig = (kk >> 1) + (kk & 1) * (g.CPG / 2);
@@ -243,6 +254,33 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   for (int r = 0; r < 4; ++r) {
     const int p = p0 + ty + 8 * r, c = c0 + tx;
     if (c < C && p < PP) ob[(size_t)p * C + c] = tile[tx][ty + 8 * r];
+  }
+}
+
+// Same copy with 64-channel x 64-pixel tiles for C % 64 == 0: 256-byte segments on both the NCHW read and the NHWC write
+// side (the 32x32 tile writes 128-byte pieces: 0.87 ms instead of 0.3 ms for the 64-channel 640x640 layer at B=16).
+__global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __restrict__ in, int C, int H, int W,
+                                                              float* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int Wp = W + 3, PP = (H + 3) * Wp, HW = H * W;
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const float* ib = in + (size_t)b * C * HW;
+  float* ob = out + (size_t)b * C * PP;
+  const int pp = p0 + tx;
+  const int yy = pp / Wp - 1, xx = pp - (yy + 1) * Wp - 1;
+  const bool inside = pp < PP && yy >= 0 && yy < H && xx >= 0 && xx < W;
+  const int src = yy * W + xx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + ty + 4 * r;
+    tile[ty + 4 * r][tx] = inside ? ib[(size_t)c * HW + src] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int p = p0 + ty + 4 * r;
+    if (p < PP) ob[(size_t)p * C + c0 + tx] = tile[tx][ty + 4 * r];
   }
 }
 
@@ -575,6 +613,180 @@ __global__ void __launch_bounds__(256) dcn_bwd_data_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward (offset / mask gradients only; grad_input not requested -- the C2-Matching case).
+// Same MFMA product as dcn_bwd_data_kernel (dCol tile = Wb^T . gO, gO resident), but built on the forward's footing:
+//   * gathers from the zero-bordered channels-last copy, float4 per 4 channels, no validity logic;
+//   * the K rows of a tile are ordered (weight_relayout_kernel, order 2) so that every lane owns complete (tap, group)s of
+//     its pixel -- both halves of one for 32-channel groups, combined with one cross-half add: grad_offset and grad_mask
+//     (dcn_v2_im2col_cuda.cu:257-330) are plain coalesced stores, written exactly once -- no atomics, no zero fill;
+//   * raw offsets, sampling state and gathers of a tile are issued in front of its MFMA chain (COH MFMAs cover them).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int COH, int CPG>
+__global__ void __launch_bounds__(256) dcn_bwd_offmask_kernel(const float* __restrict__ inl, const float* __restrict__ wb,
+                                                               const float* __restrict__ offset,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ gout, Geom g,
+                                                               float* __restrict__ goff, float* __restrict__ gmsk) {
+  constexpr int NGL = CPG == 8 ? 2 : 1;   // groups (half a group for CPG = 32) per lane and k tile
+  constexpr int CPL = 16 / NGL;           // channels per lane and group
+  constexpr int NQ = CPL / 4;
+  constexpr int ROWS = 2 * COH;           // rows of Wb (output channels, padded) = rows of a staged tile
+  constexpr int TILE = ROWS * 32;         // floats per staged k tile: Wb[o][kt*32 .. kt*32+32)
+  extern __shared__ __attribute__((aligned(16))) float wtile[];   // [2][ROWS][32]
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int HWo = g.Ho * g.Wo;
+  const int p0 = (blockIdx.x * 4 + wv) * 32;   // may lie beyond HWo for the last waves: they still hit the barriers
+  const int p = p0 + j;
+  const bool pok = p < HWo;
+  const int pc = min(p, HWo - 1);
+  const int py = pc / g.Wo, px = pc - py * g.Wo;
+  const int Wp = g.W + 3;
+  const float* in_b = inl + (size_t)b * g.C * (g.H + 3) * Wp;
+  const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
+  const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
+  const float* go_b = gout + (size_t)b * g.Co * HWo;
+  float* goff_b = goff + (size_t)b * g.dg * 2 * g.T * HWo;
+  float* gmsk_b = gmsk + (size_t)b * g.dg * g.T * HWo;
+  const float fy = (float)(py * g.sh - g.ph), fx = (float)(px * g.sw - g.pw);
+  const float Hf = (float)g.H, Wf = (float)g.W;
+
+  // B operand: gO[o = 2t + hi][pixel j], resident
+  float gq[COH];
+#pragma unroll
+  for (int t = 0; t < COH; ++t) {
+    const int o = 2 * t + hi;
+    gq[t] = (o < g.Co && pok) ? go_b[(size_t)o * HWo + pc] : 0.0f;
+  }
+
+  const int tpt = g.C / 32;        // k tiles per tap
+  const int nkt = g.T * tpt;
+  const int kt_per = (nkt + gridDim.z - 1) / gridDim.z;   // k tiles are independent: grid.z splits them for small batches
+  const int kt_beg = blockIdx.z * kt_per, kt_end = min(nkt, (int)(blockIdx.z + 1) * kt_per);
+
+  // A operands: the Wb tile of k tile kt (ROWS x 128 bytes) is DMA'd into LDS once per workgroup and shared by its four
+  // waves (one dword per MFMA straight from global memory left each MFMA waiting for its own load).  One instruction
+  // moves 8 rows (lane = row l>>3, 16-byte piece l&7); wave wv moves rows [wv*ROWS/4, (wv+1)*ROWS/4).
+  auto stage = [&](int kt, int buf) {
+    const float* src = wb + (size_t)(wv * (ROWS / 4) + (l >> 3)) * g.KtotPad + kt * 32 + 4 * (l & 7);
+    float* dst = wtile + buf * TILE + wv * (ROWS / 4) * 32;
+#pragma unroll
+    for (int m = 0; m < ROWS / 32; ++m) glds_b128(src + (size_t)(8 * m) * g.KtotPad, dst + 8 * m * 32);
+  };
+  // raw offsets / mask of a tile, fetched one tile ahead
+  struct Raw { float oh[NGL], ow[NGL], mk[NGL]; };
+  auto group_of = [&](int gtile, int lg) { return CPG == 32 ? gtile : (CPG == 16 ? 2 * gtile + hi : 4 * gtile + 2 * lg + hi); };
+  auto load_raw = [&](int kt, Raw& r) {
+    const int tap = kt / tpt, gtile = kt - tap * tpt;
+#pragma unroll
+    for (int lg = 0; lg < NGL; ++lg) {
+      const int gt = group_of(gtile, lg) * g.T + tap;
+      r.oh[lg] = off_b[(size_t)(2 * gt) * HWo + pc];
+      r.ow[lg] = off_b[(size_t)(2 * gt + 1) * HWo + pc];
+      r.mk[lg] = msk_b[(size_t)gt * HWo + pc];
+    }
+  };
+
+  Raw raw;
+  if (kt_beg < kt_end) {
+    stage(kt_beg, 0);
+    load_raw(kt_beg, raw);
+  }
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_beg) & 1;
+    const int tap = kt / tpt, gtile = kt - tap * tpt;
+    const int ti = tap / g.kw, tj = tap - ti * g.kw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt landed in wtile[buf]; every wave is done with wtile[buf ^ 1]
+    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
+
+    int gt[NGL];
+    float hh[NGL], hw[NGL], lh[NGL], lw[NGL], mk[NGL];
+    bool inside[NGL];
+    f32x4 v[NGL][4][NQ];
+#pragma unroll
+    for (int lg = 0; lg < NGL; ++lg) {
+      const int grp = group_of(gtile, lg);
+      gt[lg] = grp * g.T + tap;
+      mk[lg] = raw.mk[lg];
+      const float ar = (fy + (float)(ti * g.dh)) + raw.oh[lg], ac = (fx + (float)(tj * g.dw)) + raw.ow[lg];
+      inside[lg] = ar > -1.0f && ac > -1.0f && ar < Hf && ac < Wf;   // (:180, :82-87)
+      const float ah = __builtin_amdgcn_fmed3f(ar, -1.0f, Hf), aw = __builtin_amdgcn_fmed3f(ac, -1.0f, Wf);
+      const float fh = floorf(ah), fw = floorf(aw);
+      lh[lg] = ah - fh; lw[lg] = aw - fw; hh[lg] = 1.0f - lh[lg]; hw[lg] = 1.0f - lw[lg];
+      const unsigned o1 = (unsigned)(((int)fh * Wp + (int)fw + Wp + 1) * g.C + grp * CPG + (CPG == 32 ? 16 * hi : 0));
+      const unsigned o2 = o1 + (unsigned)g.C, o3 = o1 + (unsigned)(Wp * g.C), o4 = o3 + (unsigned)g.C;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        v[lg][0][q] = *reinterpret_cast<const f32x4*>(in_b + o1 + 4 * q);
+        v[lg][1][q] = *reinterpret_cast<const f32x4*>(in_b + o2 + 4 * q);
+        v[lg][2][q] = *reinterpret_cast<const f32x4*>(in_b + o3 + 4 * q);
+        v[lg][3][q] = *reinterpret_cast<const f32x4*>(in_b + o4 + 4 * q);
+      }
+    }
+    if (kt + 1 < kt_end) load_raw(kt + 1, raw);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // dCol tile: A[i = k row j][kk = o parity hi] of k-pair t = wtile[buf][2t + hi][j]; operands of 8 k-pairs are read one
+    // group ahead of the MFMAs that use them
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* wa = wtile + buf * TILE + l;   // + t * 64
+    constexpr int AG = 8;
+    float aq[2][AG];
+#pragma unroll
+    for (int t = 0; t < AG; ++t) aq[0][t] = wa[t * 64];
+#pragma unroll
+    for (int tg = 0; tg < COH / AG; ++tg) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[tg & 1][0], gq[tg * AG], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tg + 1 < COH / AG) {
+#pragma unroll
+        for (int t = 0; t < AG; ++t) aq[(tg + 1) & 1][t] = wa[((tg + 1) * AG + t) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 1; t < AG; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[tg & 1][t], gq[tg * AG + t], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // acc[li] = dCol of this lane's channel li (weight_relayout_kernel, order 2)
+#pragma unroll
+    for (int lg = 0; lg < NGL; ++lg) {
+      const float w1 = hh[lg] * hw[lg], w2 = hh[lg] * lw[lg], w3 = lh[lg] * hw[lg], w4 = lh[lg] * lw[lg];
+      float mval = 0.0f, soh = 0.0f, sow = 0.0f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const float dc = acc[lg * CPL + c];
+        const float v1 = v[lg][0][c >> 2][c & 3], v2 = v[lg][1][c >> 2][c & 3];
+        const float v3 = v[lg][2][c >> 2][c & 3], v4 = v[lg][3][c >> 2][c & 3];
+        // grad_mask (:307-310): dCol * unmasked bilinear value
+        mval = fmaf(dc, fmaf(w4, v4, fmaf(w3, v3, fmaf(w2, v2, w1 * v1))), mval);
+        // dmcn_get_coordinate_weight (:82-123); border corners read 0
+        soh = fmaf(dc, fmaf(lw[lg], v4 - v2, hw[lg] * (v3 - v1)), soh);
+        sow = fmaf(dc, fmaf(lh[lg], v4 - v3, hh[lg] * (v2 - v1)), sow);
+      }
+      soh *= mk[lg];   // val += weight * dCol * mask (:317), mask factored out of the channel sum
+      sow *= mk[lg];
+      if (CPG == 32) {   // the other half-wave holds the other 16 channels of the same (pixel, group, tap)
+        mval += __shfl_xor(mval, 32, 64);
+        soh += __shfl_xor(soh, 32, 64);
+        sow += __shfl_xor(sow, 32, 64);
+      }
+      if (!inside[lg]) { mval = 0.0f; soh = 0.0f; sow = 0.0f; }
+      if (pok && (CPG != 32 || hi == 0)) {
+        gmsk_b[(size_t)gt[lg] * HWo + pc] = mval;
+        goff_b[(size_t)(2 * gt[lg]) * HWo + pc] = soh;
+        goff_b[(size_t)(2 * gt[lg] + 1) * HWo + pc] = sow;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward (weight): grad_weight[o][k] += sum_pixels gO[o][p] * col[k][p]; one workgroup = 32 k rows x all Co x a
 // range of 64-pixel chunks (split-K).  Chunks are staged in LDS: lanes <-> pixels while gathering, rows as operands.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -854,9 +1066,14 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
   hipStream_t st = as_stream(stream);
   float* wt = static_cast<float*>(workspace);
   float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
-  if (nhwc)
-    hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
-                       st, input, C, H, W, inl);
+  if (nhwc) {
+    if (C % 64 == 0)
+      hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
+                         input, C, H, W, inl);
+    else
+      hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
+                         st, input, C, H, W, inl);
+  }
   // 8-channel groups are processed as virtual groups of two (see SPLITG): the kernel and the weight re-layout see the
   // virtual grouping, which leaves the K order a plain (tap, group, kk) order over real channels.  (Measured, B=16: large
   // layer 16.4 -> 13.7 ms on random flows, 7.6 -> 7.1 ms on coherent ones; 16-channel groups lose 2-10 %, so they stay.)
@@ -903,15 +1120,39 @@ int launch_bwd_weight(hipStream_t st, dim3 grid, const float* in, const float* o
 }
 
 struct BwdWs {
-  size_t wb, total;
+  size_t wb, inl, total;
   int CoPad2;
+  bool nhwc;   // geometry admits the atomic-free offset/mask kernel (used when grad_input is not requested)
 };
 inline BwdWs bwd_ws(const Geom& g) {
   BwdWs w;
   w.CoPad2 = copad2(g.Co);
+  w.nhwc = (g.CPG == 8 || g.CPG == 16 || g.CPG == 32) && g.C % 32 == 0;
   w.wb = 0;
-  w.total = align256(sizeof(float) * (size_t)(w.CoPad2 > 0 ? w.CoPad2 : 0) * g.KtotPad);
+  w.inl = align256(sizeof(float) * (size_t)(w.CoPad2 > 0 ? w.CoPad2 : 0) * g.KtotPad);
+  w.total = w.inl + (w.nhwc ? align256(sizeof(float) * (size_t)g.B * g.C * (g.H + 3) * (g.W + 3)) : 0);
   return w;
+}
+
+template <int COH, int CPG>
+int launch_bwd_offmask_cpg(hipStream_t st, dim3 grid, const float* inl, const float* wb, const float* off,
+                           const float* msk, const float* go, const Geom& g, float* goff, float* gmsk) {
+  const size_t lds = sizeof(float) * 2 * (size_t)(2 * COH) * 32;   // two staged Wb tiles
+  static unsigned long long lds_set = 0;
+  if (lds > 48 * 1024)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_bwd_offmask_kernel<COH, CPG>), lds, lds_set))
+      return rc;
+  hipLaunchKernelGGL((dcn::dcn_bwd_offmask_kernel<COH, CPG>), grid, dim3(256), lds, st, inl, wb, off, msk, go, g, goff, gmsk);
+  return C2M_OK;
+}
+template <int COH>
+int launch_bwd_offmask(hipStream_t st, dim3 grid, const float* inl, const float* wb, const float* off, const float* msk,
+                       const float* go, const Geom& g, float* goff, float* gmsk) {
+  switch (g.CPG) {
+    case 8: return launch_bwd_offmask_cpg<COH, 8>(st, grid, inl, wb, off, msk, go, g, goff, gmsk);
+    case 16: return launch_bwd_offmask_cpg<COH, 16>(st, grid, inl, wb, off, msk, go, g, goff, gmsk);
+    default: return launch_bwd_offmask_cpg<COH, 32>(st, grid, inl, wb, off, msk, go, g, goff, gmsk);
+  }
 }
 }  // namespace
 
@@ -941,16 +1182,37 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   float* wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.wb);
   const int HW = H * W, HWo = g.Ho * g.Wo;
 
+  // grad_input not requested + channels-last geometry: offset/mask gradients by plain stores (no zero fill needed)
+  const bool offmask = !grad_input && ws.nhwc;
   hipError_t e = grad_input ? hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * C * HW, st) : hipSuccess;
-  if (e == hipSuccess) e = hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * dg * 2 * g.T * HWo, st);
-  if (e == hipSuccess) e = hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * dg * g.T * HWo, st);
+  if (e == hipSuccess && !offmask) e = hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * dg * 2 * g.T * HWo, st);
+  if (e == hipSuccess && !offmask) e = hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * dg * g.T * HWo, st);
   if (e == hipSuccess) e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)Co * C * g.T, st);
   if (e != hipSuccess) { set_last_error(e); return C2M_ERR_LAUNCH; }
 
   hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(max(g.CoPad, ws.CoPad2) * g.KtotPad, 256)), dim3(256), 0,
-                     st, weight, g, ws.CoPad2, 0, (float*)nullptr, wb);
+                     st, weight, g, ws.CoPad2, offmask ? 2 : 0, (float*)nullptr, wb);
   if ((rc = check_launch()) != C2M_OK) return rc;
-  {
+  if (offmask) {
+    float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.inl);
+    if (C % 64 == 0)
+      hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
+                         input, C, H, W, inl);
+    else
+      hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
+                         st, input, C, H, W, inl);
+    ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
+    const int nkt = g.KtotPad / 32;
+    int nz = ceil_div(2048, ceil_div(HWo, 128) * B);
+    nz = nz < 1 ? 1 : (nz > nkt ? nkt : nz);
+    dim3 grid(ceil_div(HWo, 128), B, nz);
+    switch (ws.CoPad2) {
+      case 64: rc = launch_bwd_offmask<32>(st, grid, inl, wb, offset, mask, grad_output, g, grad_offset, grad_mask); break;
+      case 128: rc = launch_bwd_offmask<64>(st, grid, inl, wb, offset, mask, grad_output, g, grad_offset, grad_mask); break;
+      default: rc = launch_bwd_offmask<128>(st, grid, inl, wb, offset, mask, grad_output, g, grad_offset, grad_mask); break;
+    }
+    if (rc != C2M_OK) return rc;
+  } else {
     ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
     const int nkt = g.KtotPad / 32;
     int nz = ceil_div(2048, ceil_div(HWo, 128) * B);

@@ -52,7 +52,13 @@ def timed(fn, iters, name):
     torch.cuda.synchronize()
     recs = c2m_amd.profile_collect()
     c2m_amd.profile_enable(False)
-    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    out = {"call_ms": [e0.elapsed_time(e1) / iters]}   # whole operator call: staging copy, weight re-layout, kernel
     for k, ms in recs:
         out.setdefault(k, []).append(ms)
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -75,7 +81,7 @@ def main():
             t = timed(lambda: ops.dcn_v2_forward(x, w, b, off, msk, 1, 1, 1, 8), args.iters, name)
             flops = 2.0 * C * 9 * C * H * H * args.batch
             ms = t["dcn_v2_forward"]
-            res["forward"].append({"layer": name, "flow": flow, "C": C, "H": H, "B": args.batch, "ms": ms,
+            res["forward"].append({"layer": name, "flow": flow, "C": C, "H": H, "B": args.batch, "ms": ms, "call_ms": t["call_ms"],
                                    "tflops": flops / ms / 1e9, "frac_fp32_mfma_peak": flops / ms / 1e9 / PEAK})
             del x, w, b, off, msk
             torch.cuda.empty_cache()
@@ -84,9 +90,12 @@ def main():
         x, w, b, off, msk = make_inputs(args.bwd_batch, C, H, 8, dev, 2, args.bwd_lr, flow)
         go = torch.randn_like(x)
         t = timed(lambda: ops.dcn_v2_backward(x, w, b, off, msk, go, 1, 1, 1, 8), args.iters, name)
+        t2 = timed(lambda: ops.dcn_v2_backward(x, w, b, off, msk, go, 1, 1, 1, 8, need_input_grad=False), args.iters, name)
         flops = 2.0 * C * 9 * C * H * H * args.bwd_batch
         res["backward"].append({"layer": name, "flow": flow, "C": C, "H": H, "B": args.bwd_batch,
-                                "data_ms": t.get("dcn_v2_backward_data"), "weight_ms": t.get("dcn_v2_backward_weight"),
+                                "data_ms": t.get("dcn_v2_backward_data"),
+                                "data_ms_no_grad_input": t2.get("dcn_v2_backward_data"), "call_ms_no_grad_input": t2["call_ms"],
+                                "weight_ms": t.get("dcn_v2_backward_weight"),
                                 "data_tflops": flops / t["dcn_v2_backward_data"] / 1e9,
                                 "weight_tflops": flops / t["dcn_v2_backward_weight"] / 1e9})
     print(json.dumps(res))

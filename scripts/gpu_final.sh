@@ -7,6 +7,7 @@ timeout 1500 python -m pytest tests -m gpu -q -rA 2>&1 | tail -50 > gpurun_out/p
 timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; echo "rc=$?" >> gpurun_out/bench_default.log
 timeout 900 python scripts/bench_dcn.py > gpurun_out/bench_dcn.log 2>&1
 timeout 900 python scripts/bench_restore.py > gpurun_out/bench_restore.log 2>&1
+timeout 600 python scripts/bench_train.py > gpurun_out/bench_train.log 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_corr -o corr -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/rocprof_corr.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_dcn -o dcn -- python $R/scripts/bench_dcn.py --iters 2 > $R/gpurun_out/rocprof_dcn.log 2>&1

@@ -86,6 +86,20 @@ def test_batched_samples_are_independent(env, dev):
         assert np.array_equal(idx[b].cpu().numpy(), oi) and np.array_equal(val[b].cpu().numpy(), ov)
 
 
+def test_exact_ties_across_x_tiles_and_rows(env, dev):
+    """A ref map that repeats with period 12 horizontally and 10 vertically: every patch has exact duplicates in other
+    28-column x-tiles of the sweep (visited later, some with LOWER index) and in other rows.  The reference's
+    "first maximum" (lowest flat index) must win whichever tile finds it -- for both row-DMA flavours."""
+    ops, oracle, synth = env
+    for wr in (72, 70):   # 72: dwordx4 row DMA, 70: dword row DMA
+        fi = oracle.feature_normalize(synth.gaussish((256, 20, 21), 51))
+        base = synth.gaussish((256, 10, 12), 52)
+        fr = oracle.feature_normalize(np.tile(base, (1, 4, 6))[:, :37, :wr].copy())
+        gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr)
+        assert np.array_equal(gi, oi) and np.array_equal(gv, ov)
+        assert int(oi.max()) < 10 * (wr - 2)   # ties resolved into the first vertical period
+
+
 def test_midsize_80(env, dev):
     ops, oracle, synth = env
     fi = oracle.feature_normalize(synth.gaussish((256, 80, 80), 81))

@@ -43,6 +43,9 @@ SHAPES = [
     (3, 64, 33, 21, 64, 3, 3, (1, 1), (1, 1), (1, 1), 8),     # large (:124-132), ragged pixel count
     (1, 8, 10, 13, 5, 3, 2, (2, 1), (1, 2), (1, 2), 2),       # strides / dilation / non-square kernel / Co not % 32
     (1, 16, 9, 9, 40, 1, 1, (1, 1), (0, 0), (1, 1), 4),       # 1x1 kernel, Co = 40
+    (1, 48, 11, 9, 24, 3, 3, (1, 1), (1, 1), (1, 1), 6),      # 8-channel groups, dg % 4 != 0: channels-last path without group pairing
+    (1, 24, 7, 8, 16, 3, 3, (1, 1), (1, 1), (1, 1), 3),       # odd group count: NCHW kernel
+    (2, 64, 9, 10, 96, 3, 3, (2, 2), (1, 1), (1, 1), 2),      # 32-channel groups, Co = 96 (padded m-tiles), stride 2
 ]
 
 
@@ -93,17 +96,35 @@ def test_backward_is_overwriting_not_accumulating(env, dev):
         assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
 
 
-def test_backward_without_input_grad(env, dev):
-    """grad_input is optional at the C-ABI (NULL pointer): the other four gradients must not change."""
-    ops, _, synth = env
-    B, C, H, W, Co, dg = 2, 64, 11, 13, 64, 8
-    x, w, b, off, msk = _case(synth, B, C, H, W, Co, 3, 3, (1, 1), (1, 1), (1, 1), dg, 520)
-    args = [_t(a, dev) for a in (x, w, b, off, msk)] + [_t(synth.gaussish((B, Co, H, W), 521), dev)]
-    full = ops.dcn_v2_backward(*args, 1, 1, 1, dg)
-    part = ops.dcn_v2_backward(*args, 1, 1, 1, dg, need_input_grad=False)
+@pytest.mark.parametrize("cfg", [
+    # B, C, H, W, Co, stride, dg      -> channels per group
+    (2, 64, 11, 13, 64, (1, 1), 8),    # 8: two whole groups per lane
+    (2, 128, 9, 10, 128, (1, 1), 8),   # 16: one whole group per lane
+    (1, 256, 7, 9, 256, (1, 1), 8),    # 32: half a group per lane, cross-half add
+    (2, 64, 9, 10, 96, (2, 2), 2),     # 32, stride 2, Co = 96
+    (1, 48, 8, 9, 24, (1, 1), 6),      # C % 32 != 0: stays on the atomic kernel
+])
+def test_backward_without_input_grad(env, dev, cfg):
+    """grad_input is optional at the C-ABI (NULL pointer).  The other four gradients must not change -- although
+    grad_offset / grad_mask then come from a different kernel (dcn_bwd_offmask_kernel: channels-last gathers, plain
+    stores instead of atomics) -- and must still match the oracle."""
+    ops, oracle, synth = env
+    B, C, H, W, Co, st, dg = cfg
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, 3, 3, st, (1, 1), (1, 1), dg, 520)
+    Ho, Wo = off.shape[2:]
+    go = synth.gaussish((B, Co, Ho, Wo), 521)
+    args = [_t(a, dev) for a in (x, w, b, off, msk, go)]
+    full = ops.dcn_v2_backward(*args, st, 1, 1, dg)
+    # the outputs are torch.empty() blocks (recycled memory): the offset/mask kernel must write every element itself
+    part = ops.dcn_v2_backward(*args, st, 1, 1, dg, need_input_grad=False)
     assert part[0] is None
     for a, b_ in zip(full[1:], part[1:]):
         assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+    want = oracle.dcn_v2_backward(x, w, b, off, msk, go, st, (1, 1), (1, 1), dg)
+    for name, g_, w_ in zip(("grad_offset", "grad_mask"), part[1:3], want[1:3]):
+        g_ = g_.cpu().numpy()
+        tol = 1e-4 * max(1.0, float(np.abs(w_).max()))
+        assert float(np.abs(g_ - w_).max()) <= tol, f"{name}: max err {np.abs(g_ - w_).max()} > {tol}"
 
 
 def test_fuse_offsets_matches_reference_formula(env, dev):
