@@ -793,7 +793,10 @@ __global__ void __launch_bounds__(256) dcn_bwd_offmask_kernel(const float* __res
 constexpr int PCH = 64;        // pixels per chunk
 constexpr int LDP = PCH + 1;   // padded row stride: conflict-free column reads
 
-template <int MT>  // CoPad / 32
+// NHWC: `in` is the zero-bordered channels-last copy (nchw_to_nhwc*_kernel) and CPG % 8 == 0: the 8 column rows a lane
+// regenerates are 8 consecutive channels of one (group, tap) = two float4 gathers per corner instead of 32 scattered
+// dword loads, and the sampling state needs no validity logic.
+template <int MT, bool NHWC>  // MT = CoPad / 32
 __global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ offset,
                                                               const float* __restrict__ mask,
@@ -807,6 +810,7 @@ __global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(const float* __rest
   const int kt = blockIdx.x, split = blockIdx.y;
   const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
   constexpr int MPW = (MT + 3) / 4;  // m-tiles per wave
+  constexpr int KS = !NHWC ? 1 : (MT == 1 ? 4 : (MT == 2 ? 2 : 1));   // pixel-pair split across waves (channels-last path)
   f32x16 acc[MPW];
 #pragma unroll
   for (int s = 0; s < MPW; ++s)
@@ -818,45 +822,127 @@ __global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(const float* __rest
   __syncthreads();
 
   const int total = g.B * chunks_per_b;
-  for (int ch = split; ch < total; ch += nsplit) {
-    const int b = ch / chunks_per_b, pc0 = (ch - b * chunks_per_b) * PCH;
-    const int p = pc0 + l;
-    const bool pok = p < HWo;
-    const int pc = min(p, HWo - 1);
-    const int py = pc / g.Wo, px = pc - py * g.Wo;
-    const float* in_b = in + (size_t)b * g.C * HW;
-    const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
-    const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
-    const float* go_b = gout + (size_t)b * g.Co * HWo;
-    // gO chunk: wave wv loads rows wv, wv+4, ... (coalesced along pixels)
-    for (int o = wv; o < g.Co; o += 4) go_l[o * LDP + l] = pok ? go_b[(size_t)o * HWo + pc] : 0.0f;
-    // column rows 8wv .. 8wv+7 of this k tile
-    int gt_prev = -1;
-    Tap tp;
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = 8 * wv + rr, k = kt * 32 + row;
-      float v = 0.0f;
-      if (k < g.Ktot) {
-        const int gt = k / g.CPG, cig = k - gt * g.CPG;
-        const int grp = gt / g.T, tap = gt - grp * g.T;
-        if (gt != gt_prev) { tp = make_tap(g, off_b, msk_b, grp, tap, py, px, pc, pok); gt_prev = gt; }
-        float v1, v2, v3, v4;
-        v = tap_sample(tp, in_b + (size_t)(grp * g.CPG + cig) * HW, v1, v2, v3, v4) * tp.mk;
-      }
-      col_l[row * LDP + l] = v;
-    }
-    __syncthreads();
+  if constexpr (NHWC) {
+    // Chunk pipeline: the gO rows and the gathered corners of chunk n+1 are requested right after the barrier that
+    // publishes chunk n and land in registers while the MFMAs of chunk n run; they are blended / written to LDS after
+    // the second barrier.
+    constexpr int NGO = MT * 8;          // gO rows per wave and chunk (rows wv, wv+4, ...)
+    const int Wp = g.W + 3;
+    const int k0 = kt * 32 + 8 * wv;     // this wave regenerates column rows k0 .. k0+7: 8 channels of one (group, tap)
+    const int gt = k0 / g.CPG, cig0 = k0 - gt * g.CPG;
+    const int grp = gt / g.T, tap = gt - grp * g.T;
+    const int ti = tap / g.kw, tj = tap - ti * g.kw;
+    float gor[NGO], w1, w2, w3, w4;
+    f32x4 cv[4][2];
+    auto fetch = [&](int ch) {
+      const int b = ch / chunks_per_b, pc0 = (ch - b * chunks_per_b) * PCH;
+      const int p = pc0 + l;
+      const bool pok = p < HWo;
+      const int pc = min(p, HWo - 1);
+      const int py = pc / g.Wo, px = pc - py * g.Wo;
+      const float* in_b = in + (size_t)b * g.C * (g.H + 3) * Wp;
+      const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
+      const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
+      const float* go_b = gout + (size_t)b * g.Co * HWo;
+      const float oh = off_b[(size_t)(2 * gt) * HWo + pc], ow = off_b[(size_t)(2 * gt + 1) * HWo + pc];
+      const float mk = pok ? msk_b[(size_t)gt * HWo + pc] : 0.0f;
 #pragma unroll
-    for (int s = 0; s < MPW; ++s) {
-      const int mt = wv + 4 * s;
-      if (mt < MT) {
-        const float* ar = go_l + (mt * 32 + j) * LDP + hi;   // A[i = o][kk = pixel parity]
-        const float* br = col_l + j * LDP + hi;              // B[kk = pixel parity][j = k row]
-#pragma unroll
-        for (int t = 0; t < PCH / 2; ++t) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * t], br[2 * t], acc[s], 0, 0, 0);
+      for (int r = 0; r < NGO; ++r) {
+        const int o = wv + 4 * r;
+        gor[r] = (pok && o < g.Co) ? go_b[(size_t)o * HWo + pc] : 0.0f;
       }
+      const float ah = __builtin_amdgcn_fmed3f((float)(py * g.sh - g.ph + ti * g.dh) + oh, -1.0f, (float)g.H);
+      const float aw = __builtin_amdgcn_fmed3f((float)(px * g.sw - g.pw + tj * g.dw) + ow, -1.0f, (float)g.W);
+      const float fh = floorf(ah), fw = floorf(aw);
+      const float lh = ah - fh, lw = aw - fw, hw = 1.0f - lw;
+      const float mh = (1.0f - lh) * mk, ml = lh * mk;
+      w1 = mh * hw; w2 = mh * lw; w3 = ml * hw; w4 = ml * lw;
+      const float* s1 = in_b + (size_t)(((int)fh * Wp + (int)fw + Wp + 1) * g.C + grp * g.CPG + cig0);
+      const float* s3 = s1 + Wp * g.C;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        cv[0][q] = *reinterpret_cast<const f32x4*>(s1 + 4 * q);
+        cv[1][q] = *reinterpret_cast<const f32x4*>(s1 + g.C + 4 * q);
+        cv[2][q] = *reinterpret_cast<const f32x4*>(s3 + 4 * q);
+        cv[3][q] = *reinterpret_cast<const f32x4*>(s3 + g.C + 4 * q);
+      }
+    };
+    if (split < total) fetch(split);
+    for (int ch = split; ch < total; ch += nsplit) {
+#pragma unroll
+      for (int r = 0; r < NGO; ++r) go_l[(wv + 4 * r) * LDP + l] = gor[r];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          col_l[(8 * wv + 4 * q + e) * LDP + l] = fmaf(w4, cv[3][q][e], fmaf(w3, cv[2][q][e], fmaf(w2, cv[1][q][e], w1 * cv[0][q][e])));
+      __syncthreads();
+      if (ch + nsplit < total) fetch(ch + nsplit);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (KS > 1) {
+        // fewer than 4 m-tiles: the waves also split the chunk's pixel pairs (partial sums meet in the final atomics)
+        const int mt = wv % MT, tb = (wv / MT) * (PCH / 2 / KS);
+        const float* ar = go_l + (mt * 32 + j) * LDP + hi;
+        const float* br = col_l + j * LDP + hi;
+#pragma unroll
+        for (int t = 0; t < PCH / 2 / KS; ++t)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * (tb + t)], br[2 * (tb + t)], acc[0], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < MPW; ++s) {
+          const int mt = wv + 4 * s;
+          if (mt < MT) {
+            const float* ar = go_l + (mt * 32 + j) * LDP + hi;   // A[i = o][kk = pixel parity]
+            const float* br = col_l + j * LDP + hi;              // B[kk = pixel parity][j = k row]
+#pragma unroll
+            for (int t = 0; t < PCH / 2; ++t) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * t], br[2 * t], acc[s], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int ch = split; ch < total; ch += nsplit) {
+      const int b = ch / chunks_per_b, pc0 = (ch - b * chunks_per_b) * PCH;
+      const int p = pc0 + l;
+      const bool pok = p < HWo;
+      const int pc = min(p, HWo - 1);
+      const int py = pc / g.Wo, px = pc - py * g.Wo;
+      const float* in_b = in + (size_t)b * g.C * HW;
+      const float* off_b = offset + (size_t)b * g.dg * 2 * g.T * HWo;
+      const float* msk_b = mask + (size_t)b * g.dg * g.T * HWo;
+      const float* go_b = gout + (size_t)b * g.Co * HWo;
+      // gO chunk: wave wv loads rows wv, wv+4, ... (coalesced along pixels)
+      for (int o = wv; o < g.Co; o += 4) go_l[o * LDP + l] = pok ? go_b[(size_t)o * HWo + pc] : 0.0f;
+      // column rows 8wv .. 8wv+7 of this k tile
+      int gt_prev = -1;
+      Tap tp;
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = 8 * wv + rr, k = kt * 32 + row;
+        float v = 0.0f;
+        if (k < g.Ktot) {
+          const int gt = k / g.CPG, cig = k - gt * g.CPG;
+          const int grp = gt / g.T, tap = gt - grp * g.T;
+          if (gt != gt_prev) { tp = make_tap(g, off_b, msk_b, grp, tap, py, px, pc, pok); gt_prev = gt; }
+          float v1, v2, v3, v4;
+          v = tap_sample(tp, in_b + (size_t)(grp * g.CPG + cig) * HW, v1, v2, v3, v4) * tp.mk;
+        }
+        col_l[row * LDP + l] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < MPW; ++s) {
+        const int mt = wv + 4 * s;
+        if (mt < MT) {
+          const float* ar = go_l + (mt * 32 + j) * LDP + hi;   // A[i = o][kk = pixel parity]
+          const float* br = col_l + j * LDP + hi;              // B[kk = pixel parity][j = k row]
+#pragma unroll
+          for (int t = 0; t < PCH / 2; ++t) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * t], br[2 * t], acc[s], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
   }
 
   const int k = kt * 32 + j;
@@ -866,7 +952,7 @@ __global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(const float* __rest
     const int c = grp * g.CPG + cig;
 #pragma unroll
     for (int s = 0; s < MPW; ++s) {
-      const int mt = wv + 4 * s;
+      const int mt = KS > 1 ? wv % MT : wv + 4 * s;
       if (mt < MT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1108,15 +1194,22 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
 }
 
 namespace {
-template <int MT>
-int launch_bwd_weight(hipStream_t st, dim3 grid, const float* in, const float* off, const float* msk, const float* go,
-                      const Geom& g, int chunks_per_b, int nsplit, float* gw) {
+template <int MT, bool NHWC>
+int launch_bwd_weight_l(hipStream_t st, dim3 grid, const float* in, const float* off, const float* msk, const float* go,
+                        const Geom& g, int chunks_per_b, int nsplit, float* gw) {
   const size_t lds = sizeof(float) * (size_t)(MT * 32 + 32) * dcn::LDP;
   static unsigned long long lds_set = 0;
   if (lds > 48 * 1024)
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_bwd_weight_kernel<MT>), lds, lds_set)) return rc;
-  hipLaunchKernelGGL((dcn::dcn_bwd_weight_kernel<MT>), grid, dim3(256), lds, st, in, off, msk, go, g, chunks_per_b, nsplit, gw);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_bwd_weight_kernel<MT, NHWC>), lds, lds_set)) return rc;
+  hipLaunchKernelGGL((dcn::dcn_bwd_weight_kernel<MT, NHWC>), grid, dim3(256), lds, st, in, off, msk, go, g, chunks_per_b, nsplit, gw);
   return C2M_OK;
+}
+// `inl` != nullptr selects the channels-last variant (in = bordered copy)
+template <int MT>
+int launch_bwd_weight(hipStream_t st, dim3 grid, const float* in, const float* inl, const float* off, const float* msk,
+                      const float* go, const Geom& g, int chunks_per_b, int nsplit, float* gw) {
+  if (inl) return launch_bwd_weight_l<MT, true>(st, grid, inl, off, msk, go, g, chunks_per_b, nsplit, gw);
+  return launch_bwd_weight_l<MT, false>(st, grid, in, off, msk, go, g, chunks_per_b, nsplit, gw);
 }
 
 struct BwdWs {
@@ -1193,14 +1286,17 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(max(g.CoPad, ws.CoPad2) * g.KtotPad, 256)), dim3(256), 0,
                      st, weight, g, ws.CoPad2, offmask ? 2 : 0, (float*)nullptr, wb);
   if ((rc = check_launch()) != C2M_OK) return rc;
-  if (offmask) {
-    float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.inl);
+  // zero-bordered channels-last copy of the input for the gathers of the offset/mask and weight kernels
+  float* inl = ws.nhwc ? reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.inl) : nullptr;
+  if (inl) {
     if (C % 64 == 0)
       hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
                          input, C, H, W, inl);
     else
       hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
                          st, input, C, H, W, inl);
+  }
+  if (offmask) {
     ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
     const int nkt = g.KtotPad / 32;
     int nz = ceil_div(2048, ceil_div(HWo, 128) * B);
@@ -1234,14 +1330,14 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
     const int MT = g.CoPad / 32;
     dim3 grid(nkt, nsplit);
     switch (MT) {
-      case 1: rc = launch_bwd_weight<1>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 2: rc = launch_bwd_weight<2>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 3: rc = launch_bwd_weight<3>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 4: rc = launch_bwd_weight<4>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 5: rc = launch_bwd_weight<5>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 6: rc = launch_bwd_weight<6>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      case 7: rc = launch_bwd_weight<7>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
-      default: rc = launch_bwd_weight<8>(st, grid, input, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 1: rc = launch_bwd_weight<1>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 2: rc = launch_bwd_weight<2>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 3: rc = launch_bwd_weight<3>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 4: rc = launch_bwd_weight<4>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 5: rc = launch_bwd_weight<5>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 6: rc = launch_bwd_weight<6>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      case 7: rc = launch_bwd_weight<7>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
+      default: rc = launch_bwd_weight<8>(st, grid, input, inl, offset, mask, grad_output, g, chunks_per_b, nsplit, grad_weight); break;
     }
     if (rc != C2M_OK) return rc;
   }
