@@ -84,6 +84,12 @@ def cpu_baseline(h, C, threads=None, budget_s=12.0):
         rows = want
         dt = run(rows)
     frac = (rows - 2) / (h - 2)
+    # one host thread, 8 query rows (SURVEY.md 8d asks for a 1-thread figure beside the all-core one)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    torch_port.feature_match_index_conv(fi_full[:, :8].contiguous(), fr, 3, 1, 1, True, True)
+    dt_1 = time.perf_counter() - t0
+    torch.set_num_threads(threads)
     # the C oracle (pixel-level restructuring, OpenMP) on a 48-row sample, for context
     c2m_oracle.set_num_threads(min(threads, 32))
     t0 = time.perf_counter()
@@ -92,6 +98,7 @@ def cpu_baseline(h, C, threads=None, budget_s=12.0):
     return {"value": frac / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{rows} of {h} query rows of one {h}x{h}x{C} pair vs full ref map, PyTorch-CPU conv2d+max "
                       f"(reference algorithm, oracle/torch_port.py), {dt:.2f}s; linear extrapolation to a pair",
+            "one_thread_pairs_per_s": (6 / (h - 2)) / dt_1,
             "oracle_c_openmp_pairs_per_s": (46 / (h - 2)) / dt_c, "oracle_c_threads": min(threads, 32)}
 
 

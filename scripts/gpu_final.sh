@@ -14,5 +14,6 @@ timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_dcn -o
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $R/gpurun_out/pmc_fetch -o corr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $R/gpurun_out/pmc_write -o corr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -f csv -d $R/gpurun_out/pmc_mfma -o corr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_mfma.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace -f csv -d $R/gpurun_out/pmc_dcn -o dcn -- python $R/scripts/bench_dcn.py --iters 1 > $R/gpurun_out/pmc_dcn.log 2>&1
 cd $R
 for f in $(find gpurun_out -name "*.db"); do rm -f $f; done

@@ -65,3 +65,24 @@ if ck and "FETCH_SIZE" in summary[ck[0]]:
                        "/ (GRBM_GUI_ACTIVE / 8 XCDs)."},
               open(os.path.join(REPO, "profiles", "corr_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {c: round(v["mean_per_launch"], 1) for c, v in cs.items()} for k, cs in summary.items() if "corr_argmax" in k}, indent=1))
+
+# DCNv2 kernels: MFMA busy fraction per kernel from the bench_dcn.py counter pass
+dacc = {}
+for fn in glob.glob(os.path.join(OUT, "pmc_dcn", "*counter_collection.csv")):
+    for r in csv.DictReader(open(fn)):
+        sname = short(r["Kernel_Name"])
+        if not sname or "dcn" not in sname:
+            continue
+        a = dacc.setdefault(sname, {}).setdefault(r["Counter_Name"], {})
+        a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+if dacc:
+    dsum = {}
+    for k, cs in dacc.items():
+        d = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in cs.items()}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+            d["mfma_busy_fraction"] = (d["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024.0) / (d["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
+        if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d:
+            d["wait_fraction_of_wave_cycles"] = d["SQ_WAIT_ANY"]["mean_per_launch"] / d["SQ_WAVE_CYCLES"]["mean_per_launch"]
+        dsum[k] = d
+    json.dump(dsum, open(os.path.join(REPO, "profiles", f"{tag}_dcn_pmc_counters.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: {"mfma_busy": round(v.get("mfma_busy_fraction", -1), 3), "wait": round(v.get("wait_fraction_of_wave_cycles", -1), 3)} for k, v in dsum.items()}, indent=1))
