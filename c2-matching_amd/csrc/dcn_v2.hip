@@ -321,10 +321,18 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
   int pc[NT];
   float fy[NT], fx[NT];   // sample position of tap (0, 0) without offset
   bool pok[NT];
+  // A wave's 32 pixels form an 8 x 4 patch when the output size allows it (else 32 consecutive pixels of a row): with
+  // coherent flows the bilinear corners of vertically adjacent pixels share cache lines too (5 x 9 instead of 2 x 33 texels).
+  const bool tile2d = (g.Wo % 8 == 0) && (g.Ho % 4 == 0);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int p = p0 + nt * 32 + j;
+    int p = p0 + nt * 32 + j;
     pok[nt] = p < HWo;
+    if (tile2d) {
+      const int tile = min(p0 / 32 + nt, HWo / 32 - 1), tpr = g.Wo / 8;
+      const int ty = tile / tpr, tx = tile - ty * tpr;
+      p = (ty * 4 + (j >> 3)) * g.Wo + tx * 8 + (j & 7);
+    }
     pc[nt] = min(p, HWo - 1);   // lanes past the end recompute the last pixel and simply do not store
     const int py = pc[nt] / g.Wo, px = pc[nt] - py * g.Wo;
     fy[nt] = (float)(py * g.sh - g.ph);
@@ -508,7 +516,7 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
         const float bo = bias[o];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          if (pok[nt]) out_b[(size_t)o * HWo + p0 + nt * 32 + j] = acc[mt][nt][r] + bo;
+          if (pok[nt]) out_b[(size_t)o * HWo + pc[nt]] = acc[mt][nt][r] + bo;
       }
     }
 }
