@@ -646,8 +646,13 @@ __global__ void __launch_bounds__(256) dcn_bwd_offmask_kernel(const float* __res
   const int b = blockIdx.y;
   const int HWo = g.Ho * g.Wo;
   const int p0 = (blockIdx.x * 4 + wv) * 32;   // may lie beyond HWo for the last waves: they still hit the barriers
-  const int p = p0 + j;
+  int p = p0 + j;
   const bool pok = p < HWo;
+  if ((g.Wo % 8 == 0) && (g.Ho % 4 == 0)) {   // 8 x 4 pixel patch per wave (gather locality, as in the forward kernel)
+    const int tile = min(p0 / 32, HWo / 32 - 1), tpr = g.Wo / 8;
+    const int ty = tile / tpr, tx = tile - ty * tpr;
+    p = (ty * 4 + (j >> 3)) * g.Wo + tx * 8 + (j & 7);
+  }
   const int pc = min(p, HWo - 1);
   const int py = pc / g.Wo, px = pc - py * g.Wo;
   const int Wp = g.W + 3;
