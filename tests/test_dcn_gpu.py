@@ -69,6 +69,49 @@ def test_forward_zero_offset_is_conv2d(env, dev):
     assert float((got - want).abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("C,H", [(256, 160), (128, 320), (64, 640)])
+def test_forward_full_size_properties(env, dev, C, H):
+    """The three DynAgg layers at BASELINE config-3 size (one sample of the batch; the oracle would take minutes here):
+    size-independent properties instead.  (1) zero offsets + unit mask == conv2d; (2) an integer offset field is the
+    conv2d of the translated, zero-filled input (compared off the 1-pixel frame, where the conv's own padding taps --
+    unlike the deformed ones -- never land inside the image); (3) the output is linear in the mask; (4) fractional
+    offsets: the operator equals the bilinear mix of its four integer-offset neighbours."""
+    ops, _, synth = env
+    dg = 8
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((1, C, H, H), generator=g, device=dev)
+    w = torch.randn((C, C, 3, 3), generator=g, device=dev) * (1.0 / np.sqrt(9 * C))
+    b = torch.randn((C,), generator=g, device=dev)
+    zeros = torch.zeros((1, 18 * dg, H, H), device=dev)
+    ones = torch.ones((1, 9 * dg, H, H), device=dev)
+    ref = F.conv2d(x, w, b, padding=1)
+    tol = 2e-4 * float(ref.abs().max())
+    assert float((ops.dcn_v2_forward(x, w, b, zeros, ones, 1, 1, 1, dg) - ref).abs().max()) < tol
+
+    def shifted(dy, dx):   # conv2d of the input translated by (dy, dx) with zero fill == every tap displaced by (dy, dx)
+        xs = torch.zeros_like(x)
+        ys, yd = (slice(dy, None), slice(0, H - dy)) if dy >= 0 else (slice(0, H + dy), slice(-dy, None))
+        xs_, xd = (slice(dx, None), slice(0, H - dx)) if dx >= 0 else (slice(0, H + dx), slice(-dx, None))
+        xs[:, :, yd, xd] = x[:, :, ys, xs_]
+        return F.conv2d(xs, w, None, padding=1)
+
+    def field(dy, dx):
+        off = torch.empty_like(zeros)
+        off[:, 0::2] = dy
+        off[:, 1::2] = dx
+        return off
+
+    zb = torch.zeros_like(b)
+    inner = (slice(None), slice(None), slice(1, -1), slice(1, -1))
+    got = ops.dcn_v2_forward(x, w, zb, field(3.0, -5.0), ones, 1, 1, 1, dg)
+    assert float((got - shifted(3, -5))[inner].abs().max()) < tol
+    half = ops.dcn_v2_forward(x, w, zb, field(3.0, -5.0), 0.5 * ones, 1, 1, 1, dg)
+    assert float((half - 0.5 * got).abs().max()) < tol
+    frac = ops.dcn_v2_forward(x, w, zb, field(2.25, -4.5), ones, 1, 1, 1, dg)
+    mix = 0.75 * 0.5 * (shifted(2, -5) + shifted(2, -4)) + 0.25 * 0.5 * (shifted(3, -5) + shifted(3, -4))
+    assert float((frac - mix)[inner].abs().max()) < tol
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if (s[1] // s[10]) % 4 == 0])
 def test_backward_matches_oracle(env, dev, shape):
     ops, oracle, synth = env
