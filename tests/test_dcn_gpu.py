@@ -112,6 +112,46 @@ def test_forward_full_size_properties(env, dev, C, H):
     assert float((frac - mix)[inner].abs().max()) < tol
 
 
+@pytest.mark.parametrize("C,H", [(256, 160), (128, 320), (64, 640)])
+def test_backward_full_size_finite_differences(env, dev, C, H):
+    """grad_offset / grad_mask of the three DynAgg layers at config-3 size against central differences of the forward.
+    An offset or mask element at pixel (y, x) only moves out[:, y, x], so the directional derivative of
+    L = sum(grad_out * out) is a 'C'-term sum: fp32 is precise enough.  All sample points sit at half-integer positions,
+    where the operator is exactly linear within +-0.25 (no kink inside the difference stencil)."""
+    ops, _, synth = env
+    dg, eps = 8, 0.25
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn((1, C, H, H), generator=g, device=dev)
+    w = torch.randn((C, C, 3, 3), generator=g, device=dev) * (1.0 / np.sqrt(9 * C))
+    b = torch.zeros((C,), device=dev)
+    off = torch.randint(-6, 7, (1, 18 * dg, H, H), generator=g, device=dev).float() + 0.5
+    msk = torch.rand((1, 9 * dg, H, H), generator=g, device=dev)
+    go = torch.randn((1, C, H, H), generator=g, device=dev)
+    _, g_off, g_msk, _, _ = ops.dcn_v2_backward(x, w, b, off, msk, go, 1, 1, 1, dg, need_input_grad=False)
+
+    def local_loss(o_, m_, y, xx):
+        out = ops.dcn_v2_forward(x, w, b, o_, m_, 1, 1, 1, dg)
+        return float((out[0, :, y, xx].double() * go[0, :, y, xx].double()).sum())
+
+    rs = np.random.RandomState(3)
+    for _ in range(4):
+        ch, y, xx = int(rs.randint(18 * dg)), int(rs.randint(8, H - 8)), int(rs.randint(8, H - 8))
+        op, om = off.clone(), off.clone()
+        op[0, ch, y, xx] += eps
+        om[0, ch, y, xx] -= eps
+        fd = (local_loss(op, msk, y, xx) - local_loss(om, msk, y, xx)) / (2 * eps)
+        an = float(g_off[0, ch, y, xx])
+        assert abs(fd - an) <= 2e-3 * max(1.0, abs(fd)), f"grad_offset[{ch},{y},{xx}]: analytic {an} vs finite difference {fd}"
+    for _ in range(2):
+        ch, y, xx = int(rs.randint(9 * dg)), int(rs.randint(H)), int(rs.randint(H))
+        mp, mm = msk.clone(), msk.clone()
+        mp[0, ch, y, xx] += eps
+        mm[0, ch, y, xx] -= eps
+        fd = (local_loss(off, mp, y, xx) - local_loss(off, mm, y, xx)) / (2 * eps)
+        an = float(g_msk[0, ch, y, xx])
+        assert abs(fd - an) <= 2e-3 * max(1.0, abs(fd)), f"grad_mask[{ch},{y},{xx}]: analytic {an} vs finite difference {fd}"
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if (s[1] // s[10]) % 4 == 0])
 def test_backward_matches_oracle(env, dev, shape):
     ops, oracle, synth = env
