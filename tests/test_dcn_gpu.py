@@ -152,6 +152,28 @@ def test_backward_full_size_finite_differences(env, dev, C, H):
         assert abs(fd - an) <= 2e-3 * max(1.0, abs(fd)), f"grad_mask[{ch},{y},{xx}]: analytic {an} vs finite difference {fd}"
 
 
+@pytest.mark.parametrize("C,H", [(256, 160), (128, 320), (64, 640)])
+def test_backward_full_size_weight_grad_is_conv2d_grad(env, dev, C, H):
+    """Zero offsets + unit mask: grad_weight / grad_bias (and grad_input, atomics path) of the config-3 layers must be the
+    gradients of a plain 3x3 convolution (torch autograd on the same device, fp32)."""
+    ops, _, synth = env
+    dg = 8
+    g = torch.Generator(device=dev).manual_seed(13)
+    x = torch.randn((1, C, H, H), generator=g, device=dev, requires_grad=True)
+    w = (torch.randn((C, C, 3, 3), generator=g, device=dev) * (1.0 / np.sqrt(9 * C))).requires_grad_(True)
+    b = torch.zeros((C,), device=dev, requires_grad=True)
+    go = torch.randn((1, C, H, H), generator=g, device=dev) * (1.0 / H)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(F.conv2d(x, w, b, padding=1), (x, w, b), go)
+    zeros = torch.zeros((1, 18 * dg, H, H), device=dev)
+    ones = torch.ones((1, 9 * dg, H, H), device=dev)
+    gx, _, _, gw, gb = ops.dcn_v2_backward(x.detach(), w.detach(), b.detach(), zeros, ones, go, 1, 1, 1, dg)
+    for name, a, r in (("grad_weight", gw, gw_ref), ("grad_bias", gb, gb_ref), ("grad_input", gx, gx_ref)):
+        tol = 5e-4 * max(1e-3, float(r.abs().max()))
+        assert float((a - r).abs().max()) <= tol, f"{name}: {float((a - r).abs().max())} > {tol}"
+    _, _, _, gw2, gb2 = ops.dcn_v2_backward(x.detach(), w.detach(), b.detach(), zeros, ones, go, 1, 1, 1, dg, need_input_grad=False)
+    assert float((gw2 - gw_ref).abs().max()) <= 5e-4 * max(1e-3, float(gw_ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if (s[1] // s[10]) % 4 == 0])
 def test_backward_matches_oracle(env, dev, shape):
     ops, oracle, synth = env
