@@ -7,7 +7,10 @@ Module path, class names, constructor arguments, parameter / sub-module names (=
 * offset/mask assembly of the ``*_sep*`` modules (chunk, cat, repeat over groups, (x,y)->(y,x) interleave, add,
   sigmoid -- dcn_v2.py:229-245) is one fused kernel (c2m_dcn_fuse_offsets_f32) instead of ~6 elementwise passes;
 * the "offset mean > 100" warning (dcn_v2.py:247-250) no longer blocks the stream: the mean is reduced on the device and
-  read back asynchronously; the warning is emitted at a later call once the value has arrived.
+  read back asynchronously; the warning is emitted at a later call once the value has arrived;
+* under ``torch.autocast`` (BASELINE config 5: bf16 inference) the operators take their inputs as float32 and compute in
+  float32 (the reference's extension reads ``.data<float>()`` and would misread half tensors): the surrounding
+  convolutions run in bf16, the sampling positions and the warp do not.
 """
 import logging
 import math
@@ -16,6 +19,7 @@ import _ext as _backend
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
@@ -29,6 +33,7 @@ class _DCNv2(Function):
     """autograd wrapper with the reference's argument order (dcn_v2.py:16-50)."""
 
     @staticmethod
+    @custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
         ctx.geom = (_pair(weight.shape[2:4]), _pair(stride), _pair(padding), _pair(dilation), int(deformable_groups))
         (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
@@ -38,6 +43,7 @@ class _DCNv2(Function):
 
     @staticmethod
     @once_differentiable
+    @custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias = ctx.saved_tensors
         (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
@@ -55,13 +61,17 @@ class _FusedOffsets(Function):
     """conv_offset_mask output (+ pre-offset) -> (offset, mask) in one kernel; backward is two elementwise torch ops."""
 
     @staticmethod
-    def forward(ctx, conv_out, pre_offset, deformable_groups, taps, abs_sum):
+    @custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, conv_out, pre_offset, deformable_groups, taps, abs_sum_bits):
+        # abs_sum travels as an int64 view of the float64 accumulator: custom_fwd would down-cast a float64 argument
+        abs_sum = None if abs_sum_bits is None else abs_sum_bits.view(torch.float64)
         offset, mask = _ops.dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, taps, abs_sum)
         ctx.save_for_backward(mask)
         return offset, mask
 
     @staticmethod
     @once_differentiable
+    @custom_bwd(device_type='cuda')
     def backward(ctx, g_offset, g_mask):
         (mask,) = ctx.saved_tensors
         return torch.cat((g_offset, g_mask * mask * (1 - mask)), dim=1), None, None, None, None
@@ -151,7 +161,8 @@ class _SelfOffsetDCN(DCNv2):
         if watch:
             self._watch.poll()
             abs_sum = torch.zeros(_ABS_SLOTS, dtype=torch.float64, device=raw.device)
-        offset, mask = _FusedOffsets.apply(raw, pre_offset, self.deformable_groups, self._taps, abs_sum)
+        offset, mask = _FusedOffsets.apply(raw, pre_offset, self.deformable_groups, self._taps,
+                                           None if abs_sum is None else abs_sum.view(torch.int64))
         if watch:
             self._watch.push(abs_sum, offset.numel())
         return offset, mask

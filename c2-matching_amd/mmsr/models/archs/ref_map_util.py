@@ -26,9 +26,10 @@ def sample_patches(inputs, patch_size=3, stride=1):
 
 def feature_match_index_batched(feat_input, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
                                 norm_input=False):
-    """feat_input (b, c, h, w), feat_ref (b, c, h', w') -> max_idx int64 (b, ho, wo), max_val float32 (b, ho, wo)."""
-    return _ops.feature_match_index_batched(feat_input, feat_ref, patch_size, input_stride, ref_stride, is_norm,
-                                            norm_input)
+    """feat_input (b, c, h, w), feat_ref (b, c, h', w') -> max_idx int64 (b, ho, wo), max_val float32 (b, ho, wo).
+    Half / bf16 features (autocast) are matched in float32."""
+    return _ops.feature_match_index_batched(feat_input.float(), feat_ref.float(), patch_size, input_stride, ref_stride,
+                                            is_norm, norm_input)
 
 
 def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
@@ -39,8 +40,8 @@ def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_
     max_idx int64 (ho, wo) = index of the best ref patch (row-major, lowest index on ties), max_val float32."""
     if feat_input.dim() != 3 or feat_ref.dim() != 3:
         raise ValueError("feature_match_index expects (c, h, w) tensors; use feature_match_index_batched for batches")
-    idx, val = _ops.feature_match_index_batched(feat_input[None], feat_ref[None], patch_size, input_stride, ref_stride,
-                                                is_norm, norm_input)
+    idx, val = _ops.feature_match_index_batched(feat_input[None].float(), feat_ref[None].float(), patch_size,
+                                                input_stride, ref_stride, is_norm, norm_input)
     return idx[0], val[0]
 
 

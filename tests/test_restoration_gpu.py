@@ -80,6 +80,31 @@ def test_full_chain_config1_matches_cpu_chain_built_from_oracle_ops(dev):
     assert int(idx.max()) < 38 * 38
 
 
+def test_full_chain_under_bf16_autocast(dev):
+    """BASELINE config 5 runs inference under bf16 autocast.  The plain convolutions then compute in bf16; the hot path
+    takes their outputs as float32 (custom_fwd(cast_inputs=float32) / .float()) and the SR image must stay close to the
+    fp32 one: PSNR of the difference far above the 0.02 dB budget the config allows on a ~30 dB restoration."""
+    ext, mp, g = _build_chain(dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    lq = torch.rand((1, 3, 40, 40), generator=gen, device=dev)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False)
+    ref = torch.zeros((1, 3, 160, 160), device=dev)
+    ref[:, :, :64, :64] = torch.rand((1, 3, 64, 64), generator=gen, device=dev)
+
+    def run():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        return g(lq, pre, ref_feat)
+
+    with torch.no_grad():
+        sr32 = run()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            sr16 = run()
+    assert torch.isfinite(sr16).all()
+    mse = float(((sr16.float() - sr32) ** 2).mean())
+    assert mse < 1e-3, f"bf16-autocast SR deviates from fp32: mse {mse}"   # >= 30 dB on a [0, 1] signal
+
+
 def test_stage3_training_step_runs_and_learns(dev):
     """One GPU, the reference's stage-3 MSE settings at a tiny size: loss is finite and decreases, every net_g parameter
     that the reference optimises receives a gradient (DCNv2 backward included)."""
