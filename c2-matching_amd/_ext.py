@@ -20,12 +20,13 @@ def _check(input, weight, kernel_h, kernel_w):
 
 
 def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
-                   dilation_h, dilation_w, deformable_group):
-    """-> output [B, Co, Ho, Wo] (new tensor)."""
+                   dilation_h, dilation_w, deformable_group, bf16_mma=False):
+    """-> output [B, Co, Ho, Wo] (new tensor).  `bf16_mma=True` (an extension over the reference's signature): GEMM on
+    bf16 MFMA with fp32 accumulation, tensors stay float32."""
     _check(input, weight, kernel_h, kernel_w)
     try:
         return _ops.dcn_v2_forward(input, weight, bias, offset, mask, (stride_h, stride_w), (pad_h, pad_w),
-                                   (dilation_h, dilation_w), deformable_group)
+                                   (dilation_h, dilation_w), deformable_group, bf16_mma=bf16_mma)
     except C2MError as e:
         raise RuntimeError(str(e)) from e
 

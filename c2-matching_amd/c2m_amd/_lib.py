@@ -40,6 +40,7 @@ def _declare(L):
     L.c2m_dcn_v2_backward_workspace_bytes.restype = _sz
     L.c2m_dcn_v2_backward_workspace_bytes.argtypes = [_i] * 14
     L.c2m_dcn_v2_forward_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _vp, _sz]
+    L.c2m_dcn_v2_forward_bf16mma_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _vp, _sz]
     L.c2m_dcn_v2_backward_f32.argtypes = [_vp] * 7 + [_i] * 14 + [_vp] * 5 + [_vp, _sz]
     L.c2m_dcn_fuse_offsets_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
 

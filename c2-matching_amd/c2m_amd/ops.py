@@ -90,7 +90,10 @@ def _dcn_geom(inp, weight, stride, padding, dilation):
     return (B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw), Ho, Wo
 
 
-def dcn_v2_forward(inp, weight, bias, offset, mask, stride=1, padding=1, dilation=1, deformable_groups=1):
+def dcn_v2_forward(inp, weight, bias, offset, mask, stride=1, padding=1, dilation=1, deformable_groups=1,
+                   bf16_mma=False):
+    """bf16_mma=True: the implicit GEMM runs on bf16 MFMA with fp32 accumulation (weights and blended samples rounded to
+    bf16); tensors stay float32.  For callers that asked for reduced precision (bf16 autocast), not the default."""
     inp, weight, bias, offset, mask = (_dev_f32(t, n) for t, n in
                                        ((inp, "input"), (weight, "weight"), (bias, "bias"), (offset, "offset"), (mask, "mask")))
     g, Ho, Wo = _dcn_geom(inp, weight, stride, padding, dilation)
@@ -103,9 +106,9 @@ def dcn_v2_forward(inp, weight, bias, offset, mask, stride=1, padding=1, dilatio
         nbytes = L.c2m_dcn_v2_forward_workspace_bytes(B, C, H, W, Co, kh, kw, dg)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=inp.device)
         out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=inp.device)
-        _lib.check(L.c2m_dcn_v2_forward_f32(_stream(), inp.data_ptr(), weight.data_ptr(), bias.data_ptr(),
-                                            offset.data_ptr(), mask.data_ptr(), *g, dg, out.data_ptr(), ws.data_ptr(),
-                                            nbytes), "c2m_dcn_v2_forward_f32")
+        fn = L.c2m_dcn_v2_forward_bf16mma_f32 if bf16_mma else L.c2m_dcn_v2_forward_f32
+        _lib.check(fn(_stream(), inp.data_ptr(), weight.data_ptr(), bias.data_ptr(), offset.data_ptr(), mask.data_ptr(),
+                      *g, dg, out.data_ptr(), ws.data_ptr(), nbytes), "c2m_dcn_v2_forward")
     return out
 
 

@@ -24,6 +24,8 @@
 namespace c2m {
 namespace dcn {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 struct Geom {
   int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg;
   int Ho, Wo, T, CPG, Ktot, KtotPad, CoPad;
@@ -141,6 +143,20 @@ __global__ void __launch_bounds__(256) weight_relayout_kernel(const float* __res
   }
   if (wt && o < g.CoPad) wt[(size_t)k * g.CoPad + o] = v;
   if (wb && o < CoPad2) wb[(size_t)o * g.KtotPad + k] = v;
+}
+
+// bf16 weights of the channels-last forward kernel: Wh[K/8][CoPad][8], K order (tap, group, 16-k MFMA m, half h, e) with
+// channel-in-group = h * CPG/2 + 8m + e  (`g` describes the -- possibly virtual -- grouping the kernel runs with)
+__global__ void __launch_bounds__(256) weight_relayout_bf16_kernel(const float* __restrict__ w, Geom g,
+                                                                    __bf16* __restrict__ wh) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= g.CoPad * g.Ktot) return;
+  const int k8 = e / (g.CoPad * 8), r = e - k8 * (g.CoPad * 8);
+  const int o = r >> 3, k = k8 * 8 + (r & 7);
+  const int gs = k / g.CPG, pos = k - gs * g.CPG;
+  const int tap = gs / g.dg, grp = gs - tap * g.dg;
+  const int cig = ((pos >> 3) & 1) * (g.CPG / 2) + 8 * (pos >> 4) + (pos & 7);
+  wh[e] = (__bf16)(o < g.Co ? w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap] : 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -297,7 +313,10 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __rest
 //     hi samples real group 2*grp + hi with that group's offsets/mask and owns all of its channels.  The memory layout,
 //     the K order and the weight chunks are exactly those of a real CPG-channel group; the sampling state -- the
 //     dominant VALU cost for 8- and 16-channel groups -- is computed once per 2x as many MFMAs.
-template <int MT, int NT, int CPG, int GC, bool SPLITG>
+//   * BF16: the GEMM runs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): `wt` then points to bf16 weights laid out
+//     [K/8][CoPad][8] (weight_relayout_bf16_kernel), the blended column values are rounded to bf16 (RNE) in registers.
+//     Gathers, sampling state and blend stay fp32.  For callers that ask for reduced precision (bf16 autocast).
+template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
 __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
@@ -305,8 +324,9 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
                                                                float* __restrict__ out) {
   constexpr int HALF = CPG / 2, NQ = HALF / 4;
   constexpr int MW = MT * 32;                 // output channels of this workgroup
-  constexpr int CHUNK = GC * CPG * MW;        // floats per weight chunk
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][GC*CPG][MW]
+  constexpr int CHUNK = GC * CPG * MW / (BF16 ? 2 : 1);   // floats (4-byte units) per weight chunk
+  static_assert(!BF16 || HALF % 8 == 0, "a bf16 MFMA takes 8 channels from each half-wave");
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // fp32: [2][GC*CPG][MW]; bf16: [2][GC*CPG/8][MW][8]
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y, ob = blockIdx.z;
@@ -348,14 +368,16 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
   // chunk ci = weight rows [ci*GC*CPG, (ci+1)*GC*CPG) of Wt[K][CoPad], columns [ob*MW, ob*MW + MW)
+  // (bf16: rows are k octets, one 16-byte piece per (octet, output channel))
   auto stage = [&](int ci, int buf) {   // 16-byte pieces, 64 per DMA instruction (wave-uniform LDS base + lane*16)
     constexpr int NPIECE = CHUNK / 4;
+    constexpr int PPR = BF16 ? MW : MW / 4;            // pieces per row
+    constexpr int ROWS = BF16 ? GC * CPG / 8 : GC * CPG;
     for (int pb = wv * 64; pb < NPIECE; pb += 256) {
       const int piece = pb + l;
       if (piece < NPIECE) {
-        const int f = piece * 4;          // float index inside the chunk
-        const int row = f / MW, col = f - row * MW;
-        const float* src = wt + (size_t)(ci * GC * CPG + row) * g.CoPad + ob * MW + col;
+        const int row = piece / PPR, pc_ = piece - row * PPR;
+        const float* src = wt + ((size_t)(ci * ROWS + row) * g.CoPad + ob * MW) * (BF16 ? 4 : 1) + pc_ * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(wl + buf * CHUNK + pb * 4), 16, 0, 0);
       }
@@ -454,6 +476,29 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
         c[nt] = fmaf(wA[nt].w4, gvA[nt].v4[q][e], fmaf(wA[nt].w3, gvA[nt].v3[q][e],
                 fmaf(wA[nt].w2, gvA[nt].v2[q][e], wA[nt].w1 * gvA[nt].v1[q][e])));
     };
+    if constexpr (BF16) {
+      // one MFMA = 16 k: channels [8m, 8m+8) of this lane's half-run from each half-wave.  A operand of (m, mt): the 8 bf16
+      // of k octet (gi*CPG/8 + 2m + hi), output channel mt*32 + j -- one conflict-free ds_read_b128.
+      const bf16x8* wrow = reinterpret_cast<const bf16x8*>(wl + (ci & 1) * CHUNK) + (gi * (CPG / 8) + hi) * MW + j;
+#pragma unroll
+      for (int m = 0; m < HALF / 8; ++m) {
+        bf16x8 vb[NT];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float c[NT];
+          blend(8 * m + e, c);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) vb[nt][e] = (__bf16)c[nt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 a = wrow[(2 * m) * MW + mt * 32];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vb[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    } else {
     // MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
     const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
     float aop[2][MT], col[2][NT];
@@ -474,6 +519,7 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __res
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[t & 1][mt], col[t & 1][nt], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1080,38 +1126,38 @@ inline int copad_fwd(int Co) {
 }
 inline int copad2(int Co) { return Co <= 64 ? 64 : Co <= 128 ? 128 : Co <= 256 ? 256 : -1; }
 
-template <int MT, int NT, int CPG, int GC, bool SPLITG>
+template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
 int launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                     const float* msk, const Geom& g, float* out) {
   const int HWo = g.Ho * g.Wo;
-  const size_t lds = sizeof(float) * 2 * (size_t)GC * CPG * MT * 32;
+  const size_t lds = (BF16 ? 2 : 4) * 2 * (size_t)GC * CPG * MT * 32;
   static unsigned long long lds_set = 0;
   if (lds > 48 * 1024)
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG>), lds, lds_set))
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16>), lds, lds_set))
       return rc;
   dim3 grid(ceil_div(HWo, 4 * NT * 32), g.B, g.CoPad / (MT * 32));
-  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
+  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
   return C2M_OK;
 }
 
 // groups per weight chunk: the largest power of two dividing dg with chunk <= 32 KiB (and >= 4 KiB so that every wave's
 // quarter is a whole number of 1 KiB DMA pieces)
-template <int MT, int NT, int CPG, bool SPLITG>
+template <int MT, int NT, int CPG, bool SPLITG, bool BF16>
 int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                      const float* msk, const Geom& g, float* out) {
-  constexpr int ROWB = CPG * MT * 32 * 4;  // bytes of one group's weight rows
+  constexpr int ROWB = CPG * MT * 32 * (BF16 ? 2 : 4);  // bytes of one group's weight rows
   constexpr int FIT = (32 * 1024) / ROWB;  // groups that fit a 32 KiB chunk (>= 1 for every instantiation)
   if constexpr (FIT >= 8) {
-    if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG>(st, inl, wt, bias, off, msk, g, out);
+    if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
   }
   if constexpr (FIT >= 4) {
-    if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4, SPLITG>(st, inl, wt, bias, off, msk, g, out);
+    if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
   }
   static_assert(FIT >= 2, "two groups' weight rows must fit one chunk");
-  return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG>(st, inl, wt, bias, off, msk, g, out);   // use_nhwc() guarantees an even dg
+  return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);   // use_nhwc() guarantees an even dg
 }
 
-template <int CPG, bool SPLITG>
+template <int CPG, bool SPLITG, bool BF16>
 int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt, const float* bias, const float* off,
                       const float* msk, const Geom& g, float* out) {
   // Register budget (256 VGPRs at 2 waves/SIMD): MT*NT*16 accumulators + two generations of gathered corners
@@ -1121,9 +1167,9 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
   // latency better than a second pixel tile amortises the LDS weight reads (large layer, B=16: 10.4 -> 8.4 ms)
   constexpr int NT2 = 1;
   switch (mt) {
-    case 1: return pick_gc_fwd_nhwc<1, NT2, CPG, SPLITG>(st, inl, wt, bias, off, msk, g, out);
-    case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG>(st, inl, wt, bias, off, msk, g, out);
-    default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG>(st, inl, wt, bias, off, msk, g, out);
+    case 1: return pick_gc_fwd_nhwc<1, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
   }
 }
 
@@ -1148,10 +1194,10 @@ extern "C" size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W,
   return n;
 }
 
-extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
-                                      const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh,
-                                      int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output,
-                                      void* workspace, size_t workspace_bytes) {
+namespace {
+int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, const float* bias, const float* offset,
+                const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+                int dh, int dw, int dg, float* output, void* workspace, size_t workspace_bytes, bool want_bf16) {
   if (!input || !weight || !bias || !offset || !mask || !output) return C2M_ERR_INVALID_ARG;
   Geom g;
   int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg);
@@ -1179,18 +1225,28 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
   const bool split = nhwc && g.CPG == 8 && g.dg % 4 == 0;   // the virtual grouping must keep an even group count
   Geom gk = g;
   if (split) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
-  hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, gk, 0,
-                     nhwc ? 1 : 0, wt, (float*)nullptr);
+  // bf16 MFMA variant: channels-last geometries whose half-run is a multiple of 8 channels; anything else computes in fp32
+  const bool bf16 = want_bf16 && nhwc && gk.CPG >= 16;
+  if (bf16)
+    hipLaunchKernelGGL(dcn::weight_relayout_bf16_kernel, dim3(ceil_div(g.CoPad * g.Ktot, 256)), dim3(256), 0, st, weight, gk,
+                       reinterpret_cast<__bf16*>(wt));
+  else
+    hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, gk, 0,
+                       nhwc ? 1 : 0, wt, (float*)nullptr);
   if ((rc = check_launch()) != C2M_OK) return rc;
   if (nhwc) {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
-    if (split) {
-      rc = dispatch_fwd_nhwc<16, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, gk, output);
+    if (bf16) {
+      if (split) rc = dispatch_fwd_nhwc<16, true, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, gk, output);
+      else if (g.CPG == 16) rc = dispatch_fwd_nhwc<16, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
+      else rc = dispatch_fwd_nhwc<32, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
+    } else if (split) {
+      rc = dispatch_fwd_nhwc<16, true, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, gk, output);
     } else {
       switch (g.CPG) {
-        case 8: rc = dispatch_fwd_nhwc<8, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
-        case 16: rc = dispatch_fwd_nhwc<16, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
-        default: rc = dispatch_fwd_nhwc<32, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+        case 8: rc = dispatch_fwd_nhwc<8, false, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+        case 16: rc = dispatch_fwd_nhwc<16, false, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
+        default: rc = dispatch_fwd_nhwc<32, false, false>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output); break;
       }
     }
     if (rc != C2M_OK) return rc;
@@ -1204,6 +1260,23 @@ extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, c
     }
   }
   return check_launch();
+}
+}  // namespace
+
+extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
+                                      const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh,
+                                      int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output,
+                                      void* workspace, size_t workspace_bytes) {
+  return dcn_forward(stream, input, weight, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
+                     workspace, workspace_bytes, false);
+}
+
+extern "C" int c2m_dcn_v2_forward_bf16mma_f32(c2m_stream_t stream, const float* input, const float* weight,
+                                              const float* bias, const float* offset, const float* mask, int B, int C,
+                                              int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                              int dw, int dg, float* output, void* workspace, size_t workspace_bytes) {
+  return dcn_forward(stream, input, weight, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
+                     workspace, workspace_bytes, true);
 }
 
 namespace {

@@ -34,10 +34,11 @@ class _DCNv2(Function):
 
     @staticmethod
     @custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, bf16_mma=False):
         ctx.geom = (_pair(weight.shape[2:4]), _pair(stride), _pair(padding), _pair(dilation), int(deformable_groups))
         (kh, kw), (sh, sw), (ph, pw), (dh, dw), dg = ctx.geom
-        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg,
+                                         bf16_mma=bool(bf16_mma))
         ctx.save_for_backward(input, offset, mask, weight, bias)
         return output
 
@@ -51,10 +52,16 @@ class _DCNv2(Function):
                                                                  grad_output.contiguous(), kh, kw, sh, sw, ph, pw,
                                                                  dh, dw, dg,
                                                                  need_input_grad=ctx.needs_input_grad[0])
-        return g_in, g_off, g_mask, g_w, g_b, None, None, None, None
+        return g_in, g_off, g_mask, g_w, g_b, None, None, None, None, None
 
 
 dcn_v2_conv = _DCNv2.apply
+
+
+def _bf16_autocast():
+    """True inside `torch.autocast('cuda', dtype=torch.bfloat16)`: the caller asked for reduced precision, so the DCNv2
+    GEMM may run on bf16 MFMA (sampling positions, bilinear blend and accumulation stay float32)."""
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
 class _FusedOffsets(Function):
@@ -129,7 +136,7 @@ class DCNv2(nn.Module):
 
     def _conv(self, x, offset, mask):
         return dcn_v2_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                           self.deformable_groups)
+                           self.deformable_groups, _bf16_autocast())
 
     def forward(self, input, offset, mask):
         assert 2 * self.deformable_groups * self._taps == offset.shape[1]

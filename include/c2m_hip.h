@@ -101,6 +101,16 @@ int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float*
                            int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output, void* workspace,
                            size_t workspace_bytes);
 
+/* Same operator with the implicit GEMM on bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation): weights and the
+ * blended column values are rounded to bf16 (RNE); tensors, sampling positions, bilinear blend and bias stay float32.
+ * For callers that asked for reduced precision (the Python operator uses it under bf16 autocast, BASELINE config 5);
+ * geometries without a bf16 kernel (groups of fewer than 16 channels that cannot be paired) compute in fp32.
+ * Same workspace as c2m_dcn_v2_forward_f32. */
+int c2m_dcn_v2_forward_bf16mma_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
+                                   const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh,
+                                   int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output,
+                                   void* workspace, size_t workspace_bytes);
+
 size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                                            int pw, int dh, int dw, int dg);
 /* All gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255).  grad_input may be NULL:

@@ -81,7 +81,9 @@ def main():
             t = timed(lambda: ops.dcn_v2_forward(x, w, b, off, msk, 1, 1, 1, 8), args.iters, name)
             flops = 2.0 * C * 9 * C * H * H * args.batch
             ms = t["dcn_v2_forward"]
+            tb = timed(lambda: ops.dcn_v2_forward(x, w, b, off, msk, 1, 1, 1, 8, bf16_mma=True), args.iters, name)
             res["forward"].append({"layer": name, "flow": flow, "C": C, "H": H, "B": args.batch, "ms": ms, "call_ms": t["call_ms"],
+                                   "bf16_mma_ms": tb["dcn_v2_forward"],
                                    "tflops": flops / ms / 1e9, "frac_fp32_mfma_peak": flops / ms / 1e9 / PEAK})
             del x, w, b, off, msk
             torch.cuda.empty_cache()

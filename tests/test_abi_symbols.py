@@ -15,7 +15,7 @@ def _declared():
 def test_header_declares_the_expected_entry_points():
     names = _declared()
     for must in ("c2m_feature_match_index_f32", "c2m_feature_normalize_f32", "c2m_build_pre_offsets_f32",
-                 "c2m_dcn_v2_forward_f32", "c2m_dcn_v2_backward_f32", "c2m_dcn_fuse_offsets_f32", "c2m_abi_version"):
+                 "c2m_dcn_v2_forward_f32", "c2m_dcn_v2_forward_bf16mma_f32", "c2m_dcn_v2_backward_f32", "c2m_dcn_fuse_offsets_f32", "c2m_abi_version"):
         assert must in names
 
 

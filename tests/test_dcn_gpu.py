@@ -60,6 +60,30 @@ def test_forward_matches_oracle(env, dev, shape):
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
 
 
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[7]])
+def test_forward_bf16_mma_close_to_fp32(env, dev, shape):
+    """bf16-MFMA variant (fp32 tensors, weights and blended samples rounded to bf16, fp32 accumulation): must equal the
+    oracle evaluated on bf16-rounded weights up to the rounding of the column values -- i.e. stay within a few bf16 ulps
+    of the fp32 result in the 2-norm, and be exactly the fp32 operator when everything is bf16-representable."""
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 300)
+    args = [_t(a, dev) for a in (x, w, b, off, msk)]
+    ref = ops.dcn_v2_forward(*args, st, pd, dl, dg)
+    got = ops.dcn_v2_forward(*args, st, pd, dl, dg, bf16_mma=True)
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < 6e-3, f"bf16 MFMA forward deviates {rel} (2-norm, relative) from fp32"
+    assert rel > 0 or C // dg < 8   # it really ran the reduced-precision kernel (except where only fp32 kernels exist)
+    # integer-valued data (exactly representable in bf16, integer sample positions): identical to fp32
+    xi = torch.round(args[0] * 2).clamp(-8, 8)
+    wi = torch.round(args[1] * 64).clamp(-4, 4)
+    offi = torch.round(args[3])
+    mski = torch.ones_like(args[4])
+    a = ops.dcn_v2_forward(xi, wi, args[2], offi, mski, st, pd, dl, dg)
+    c = ops.dcn_v2_forward(xi, wi, args[2], offi, mski, st, pd, dl, dg, bf16_mma=True)
+    assert torch.equal(a, c)
+
+
 def test_forward_zero_offset_is_conv2d(env, dev):
     ops, _, synth = env
     B, C, H, W, Co, dg = 2, 64, 20, 24, 64, 8
