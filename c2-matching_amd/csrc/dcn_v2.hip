@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __rest
 //     [K/8][CoPad][8] (weight_relayout_bf16_kernel), the blended column values are rounded to bf16 (RNE) in registers.
 //     Gathers, sampling state and blend stay fp32.  For callers that ask for reduced precision (bf16 autocast).
 template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
-__global__ void __launch_bounds__(256, 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
+__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
@@ -1169,6 +1169,11 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
   switch (mt) {
     case 1: return pick_gc_fwd_nhwc<1, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
     case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    case 8:
+      // bf16: the kernel is gather/blend bound, so all 256 output channels share one gathered column (one wave per SIMD,
+      // 128 accumulator registers) instead of splitting Co over grid.z and gathering twice
+      if constexpr (BF16 && CPG == 32) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+      [[fallthrough]];
     default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
   }
 }
