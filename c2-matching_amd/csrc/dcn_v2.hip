@@ -1146,7 +1146,7 @@ template <int MT, int NT, int CPG, bool SPLITG, bool BF16>
 int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                      const float* msk, const Geom& g, float* out) {
   constexpr int ROWB = CPG * MT * 32 * (BF16 ? 2 : 4);  // bytes of one group's weight rows
-  constexpr int FIT = (32 * 1024) / ROWB;  // groups that fit a 32 KiB chunk (>= 1 for every instantiation)
+  constexpr int FIT = ((MT == 8 ? 64 : 32) * 1024) / ROWB;  // groups that fit a 32 KiB chunk (64 KiB for the one-wave-per-SIMD MT = 8 variant)
   if constexpr (FIT >= 8) {
     if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
   }
@@ -1171,7 +1171,7 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
     case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
     case 8:
       // bf16: the kernel is gather/blend bound, so all 256 output channels share one gathered column (one wave per SIMD,
-      // 128 accumulator registers) instead of splitting Co over grid.z and gathering twice
+      // 128 accumulator registers) instead of splitting Co over grid.z and gathering twice.  (fp32: measured, no gain.)
       if constexpr (BF16 && CPG == 32) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
       [[fallthrough]];
     default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
