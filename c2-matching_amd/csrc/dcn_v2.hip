@@ -249,14 +249,15 @@ __global__ void __launch_bounds__(256, 2) dcn_fwd_mfma_kernel(const float* __res
 // The copy carries a zero border: 1 pixel on the top/left, 2 on the bottom/right ((H+3) x (W+3) pixels).  A sample
 // position clamped to [-1, H] x [-1, W] then always has its four corners inside the buffer and every corner the reference
 // treats as "outside" (dcn_v2_im2col_cuda.cu:36-47, 180) reads 0 -- no per-corner validity logic in the hot loop.
+template <typename OutT>   // float, or __bf16 for the bf16-MFMA forward (halves the gather bytes)
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int H, int W,
-                                                            float* __restrict__ out) {
+                                                            OutT* __restrict__ out) {
   __shared__ float tile[32][33];
   const int Wp = W + 3, PP = (H + 3) * Wp, HW = H * W;
   const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const float* ib = in + (size_t)b * C * HW;
-  float* ob = out + (size_t)b * C * PP;
+  OutT* ob = out + (size_t)b * C * PP;
   const int pp = p0 + tx;
   const int yy = pp / Wp - 1, xx = pp - (yy + 1) * Wp - 1;
   const bool inside = pp < PP && yy >= 0 && yy < H && xx >= 0 && xx < W;
@@ -269,20 +270,21 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int p = p0 + ty + 8 * r, c = c0 + tx;
-    if (c < C && p < PP) ob[(size_t)p * C + c] = tile[tx][ty + 8 * r];
+    if (c < C && p < PP) ob[(size_t)p * C + c] = (OutT)tile[tx][ty + 8 * r];
   }
 }
 
 // Same copy with 64-channel x 64-pixel tiles for C % 64 == 0: 256-byte segments on both the NCHW read and the NHWC write
 // side (the 32x32 tile writes 128-byte pieces: 0.87 ms instead of 0.3 ms for the 64-channel 640x640 layer at B=16).
+template <typename OutT>
 __global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __restrict__ in, int C, int H, int W,
-                                                              float* __restrict__ out) {
+                                                              OutT* __restrict__ out) {
   __shared__ float tile[64][65];
   const int Wp = W + 3, PP = (H + 3) * Wp, HW = H * W;
   const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   const float* ib = in + (size_t)b * C * HW;
-  float* ob = out + (size_t)b * C * PP;
+  OutT* ob = out + (size_t)b * C * PP;
   const int pp = p0 + tx;
   const int yy = pp / Wp - 1, xx = pp - (yy + 1) * Wp - 1;
   const bool inside = pp < PP && yy >= 0 && yy < H && xx >= 0 && xx < W;
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int p = p0 + ty + 4 * r;
-    if (p < PP) ob[(size_t)p * C + c0 + tx] = tile[tx][ty + 4 * r];
+    if (p < PP) ob[(size_t)p * C + c0 + tx] = (OutT)tile[tx][ty + 4 * r];
   }
 }
 
@@ -322,7 +324,10 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
                                                                float* __restrict__ out) {
-  constexpr int HALF = CPG / 2, NQ = HALF / 4;
+  constexpr int HALF = CPG / 2;
+  constexpr int ES = BF16 ? 2 : 4;            // bytes per element of the staged channels-last copy (bf16 with the bf16 GEMM)
+  constexpr int EPV = 16 / ES;                // elements per 16-byte gather
+  constexpr int NQ = HALF / EPV;              // gathers per corner
   constexpr int MW = MT * 32;                 // output channels of this workgroup
   constexpr int CHUNK = GC * CPG * MW / (BF16 ? 2 : 1);   // floats (4-byte units) per weight chunk
   static_assert(!BF16 || HALF % 8 == 0, "a bf16 MFMA takes 8 channels from each half-wave");
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
   const int HWo = g.Ho * g.Wo;
   const int p0 = (blockIdx.x * 4 + wv) * (NT * 32);  // may lie beyond HWo for the last waves: they still hit the barriers
   const int Wp = g.W + 3;                                          // zero-bordered staging copy (nchw_to_nhwc_kernel)
-  const float* in_b = inl + (size_t)b * g.C * (g.H + 3) * Wp;
+  const char* in_b = reinterpret_cast<const char*>(inl) + (size_t)b * g.C * (g.H + 3) * Wp * ES;
   const int dg_real = SPLITG ? 2 * g.dg : g.dg;
   const float* off_b = offset + (size_t)b * dg_real * 2 * g.T * HWo;
   const float* msk_b = mask + (size_t)b * dg_real * g.T * HWo;
@@ -402,17 +407,24 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
   const unsigned lane_ch = hi * HALF;   // this lane's half-run inside its group
   const int obase = (Wp + 1) * g.C + (int)lane_ch;   // bordered pixel (1, 1) = image pixel (0, 0)
   auto gather = [&](int grp, const Samp (&sp)[NT], Gath (&gv)[NT]) {
-    const float* gb = in_b + grp * CPG;   // wave-uniform base; per-lane part stays a 32-bit element offset
+    const char* gb = in_b + grp * CPG * ES;   // wave-uniform base; per-lane part stays a 32-bit element offset
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const unsigned o1 = sp[nt].o1, o2 = o1 + (unsigned)g.C, o3 = o1 + (unsigned)(Wp * g.C), o4 = o3 + (unsigned)g.C;
+      // corner-major issue order, one base pointer + immediate offsets per corner: the 16-byte pieces of one corner's
+      // channel run share a cache line and should reach the texture path back to back (random flows: 15 % slower otherwise)
+      const f32x4* c1 = reinterpret_cast<const f32x4*>(gb + (size_t)o1 * ES);
+      const f32x4* c2 = reinterpret_cast<const f32x4*>(gb + (size_t)o2 * ES);
+      const f32x4* c3 = reinterpret_cast<const f32x4*>(gb + (size_t)o3 * ES);
+      const f32x4* c4 = reinterpret_cast<const f32x4*>(gb + (size_t)o4 * ES);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        gv[nt].v1[q] = *reinterpret_cast<const f32x4*>(gb + o1 + 4 * q);
-        gv[nt].v2[q] = *reinterpret_cast<const f32x4*>(gb + o2 + 4 * q);
-        gv[nt].v3[q] = *reinterpret_cast<const f32x4*>(gb + o3 + 4 * q);
-        gv[nt].v4[q] = *reinterpret_cast<const f32x4*>(gb + o4 + 4 * q);
-      }
+      for (int q = 0; q < NQ; ++q) gv[nt].v1[q] = c1[q];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) gv[nt].v2[q] = c2[q];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) gv[nt].v3[q] = c3[q];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) gv[nt].v4[q] = c4[q];
     }
   };
 
@@ -469,12 +481,21 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
     // oracle's (w1*v1 + ... ) * mask by rounding only -- DCNv2 parity is tolerance-based).  Software pipeline over the
     // k-pairs: the LDS read of the A operands and the blend of the B operand of k-pair t+1 are issued in front of the
     // MFMAs of k-pair t.
+    // channel t of a gathered corner: fp32 copy -> element t of the vectors; bf16 copy -> half of a dword, widened
+    auto elem = [](const f32x4 (&v)[NQ], int t) __attribute__((always_inline)) {
+      if constexpr (BF16) {
+        const float pair = v[t >> 3][(t >> 1) & 3];   // (bit_cast straight from the vector element reads element 0)
+        const unsigned wd = __builtin_bit_cast(unsigned, pair);
+        return __builtin_bit_cast(float, (t & 1) ? (wd & 0xffff0000u) : (wd << 16));
+      } else {
+        return v[t >> 2][t & 3];
+      }
+    };
     auto blend = [&](int t, float (&c)[NT]) __attribute__((always_inline)) {
-      const int q = t >> 2, e = t & 3;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        c[nt] = fmaf(wA[nt].w4, gvA[nt].v4[q][e], fmaf(wA[nt].w3, gvA[nt].v3[q][e],
-                fmaf(wA[nt].w2, gvA[nt].v2[q][e], wA[nt].w1 * gvA[nt].v1[q][e])));
+        c[nt] = fmaf(wA[nt].w4, elem(gvA[nt].v4, t), fmaf(wA[nt].w3, elem(gvA[nt].v3, t),
+                fmaf(wA[nt].w2, elem(gvA[nt].v2, t), wA[nt].w1 * elem(gvA[nt].v1, t))));
     };
     if constexpr (BF16) {
       // one MFMA = 16 k: channels [8m, 8m+8) of this lane's half-run from each half-wave.  A operand of (m, mt): the 8 bf16
@@ -1200,6 +1221,17 @@ extern "C" size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W,
 }
 
 namespace {
+// zero-bordered channels-last copy of `input` (fp32, or bf16 for the bf16-MFMA forward)
+template <typename OutT>
+void launch_nhwc_copy(hipStream_t st, const float* input, int B, int C, int H, int W, OutT* out) {
+  if (C % 64 == 0)
+    hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel<OutT>, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
+                       input, C, H, W, out);
+  else
+    hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel<OutT>, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
+                       st, input, C, H, W, out);
+}
+
 int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, const float* bias, const float* offset,
                 const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
                 int dh, int dw, int dg, float* output, void* workspace, size_t workspace_bytes, bool want_bf16) {
@@ -1216,14 +1248,6 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
   hipStream_t st = as_stream(stream);
   float* wt = static_cast<float*>(workspace);
   float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
-  if (nhwc) {
-    if (C % 64 == 0)
-      hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
-                         input, C, H, W, inl);
-    else
-      hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
-                         st, input, C, H, W, inl);
-  }
   // 8-channel groups are processed as virtual groups of two (see SPLITG): the kernel and the weight re-layout see the
   // virtual grouping, which leaves the K order a plain (tap, group, kk) order over real channels.  (Measured, B=16: large
   // layer 16.4 -> 13.7 ms on random flows, 7.6 -> 7.1 ms on coherent ones; 16-channel groups lose 2-10 %, so they stay.)
@@ -1232,6 +1256,10 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
   if (split) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
   // bf16 MFMA variant: channels-last geometries whose half-run is a multiple of 8 channels; anything else computes in fp32
   const bool bf16 = want_bf16 && nhwc && gk.CPG >= 16;
+  if (nhwc) {
+    if (bf16) launch_nhwc_copy(st, input, B, C, H, W, reinterpret_cast<__bf16*>(inl));
+    else launch_nhwc_copy(st, input, B, C, H, W, inl);
+  }
   if (bf16)
     hipLaunchKernelGGL(dcn::weight_relayout_bf16_kernel, dim3(ceil_div(g.CoPad * g.Ktot, 256)), dim3(256), 0, st, weight, gk,
                        reinterpret_cast<__bf16*>(wt));
@@ -1379,14 +1407,7 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   if ((rc = check_launch()) != C2M_OK) return rc;
   // zero-bordered channels-last copy of the input for the gathers of the offset/mask and weight kernels
   float* inl = ws.nhwc ? reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.inl) : nullptr;
-  if (inl) {
-    if (C % 64 == 0)
-      hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
-                         input, C, H, W, inl);
-    else
-      hipLaunchKernelGGL(dcn::nchw_to_nhwc_kernel, dim3(ceil_div((H + 3) * (W + 3), 32), ceil_div(C, 32), B), dim3(256), 0,
-                         st, input, C, H, W, inl);
-  }
+  if (inl) launch_nhwc_copy(st, input, B, C, H, W, inl);
   if (offmask) {
     ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
     const int nkt = g.KtotPad / 32;
