@@ -11,21 +11,25 @@
 // (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bit-identical to the C oracle's loop), never leaves the CU:
 //
 //   * one workgroup (8 waves) owns a 16x16 PIXEL tile of the query map = 14x14 query patches; each wave keeps its
-//     32 query pixels x C channels resident in C/2 VGPRs as MFMA A-operands for the whole sweep;
-//   * the ref map is swept in x-tiles of 32 pixels (30 patches) and, inside an x-tile, one PIXEL ROW per step;
-//     the row segment [C][32] is DMA'd global->LDS (double buffered, global_load_lds) and is the B-operand of
-//     all 8 waves;
+//     32 query pixels x C channels resident in C/2 VGPRs as MFMA A-operands for the whole sweep, rows permuted so that
+//     every lane ends up with one query pixel ROW in its 16 accumulator registers;
+//   * the ref map is swept in x-tiles of 32 pixel columns (28 patch columns) and, inside an x-tile, one PIXEL ROW per
+//     step; the row segment [C][32] is DMA'd global->LDS (double buffered, global_load_lds dwordx4) and is the
+//     B-operand of all 8 waves;
 //   * each step yields D[256 query pixels][32 ref pixels]; the three taps of one patch ROW are summed while the tile
-//     is still in the accumulator registers (two DPP wave-shifted adds per element: H[i][j] = D[i][j] + (D[i+1][j+1] +
-//     D[i+2][j+2])), and H goes to a 3-slab LDS ring (ref rows y-2, y-1, y); once row y is in, the patch row
+//     is still in the accumulator registers (two DPP wave-shifted adds per element: H[px][j] = D[px][j] + (D[px+1][j+1] +
+//     D[px+2][j+2])), and H goes to a 3-slab LDS ring (ref rows y-2, y-1, y); once row y is in, the patch row
 //     ry = y-2 is complete: lanes (= ref x) add the three row sums, scale by the precomputed inverse patch norm and
-//     update a per-lane running (max, argmin-index).  Every non-MFMA instruction costs matrix time on this chip
-//     (profiles/r01_corr_ablation.json), hence 3 LDS reads + 2 adds per candidate instead of 9 + 8;
+//     update a per-lane, per-x-tile running (max, index) with a strict compare (candidates arrive in index order inside
+//     an x-tile); the x-tile state is merged into the global one with the full (larger value, then lower index) rule.
+//     Every non-MFMA instruction costs matrix time on this chip (scripts/ubench/issue_cost.hip), hence 3 LDS reads,
+//     3 plain VALU ops, 1 compare and 2 selects per candidate;
 //   * after the sweep a 32-lane shuffle reduction with the (larger value, then lower index) rule yields the
 //     reference's "first maximum" semantics exactly, independent of the visiting order.
 //
 // LDS: ring 3*256*32*4 = 96 KiB + row buffers 2*C*32*4 = 64 KiB (C=256) = all 160 KiB of a CU; 1 workgroup per CU,
-// 2 waves per SIMD.  Roofline: MFMA (fp32 matrix peak 157.3 TF); HBM traffic is ~the compulsory 53 MB/pair.
+// 2 waves per SIMD.  Roofline: MFMA (fp32 matrix peak 157.3 TF); HBM traffic is a few times the compulsory 53 MB/pair
+// and <1 % of the HBM roofline.
 #include "c2m_common.h"
 
 namespace c2m {

@@ -5,20 +5,27 @@
 // 160x160 LR), runs batched cuBLAS SGEMMs on it and, in backward, loops over the batch on the host.  Here:
 //
 //   forward        implicit GEMM out[Co x P] = W[Co x K] . col[K x P] on fp32 MFMA (v_mfma_f32_32x32x2_f32) with the
-//                  column matrix generated in registers, already in MFMA B-operand layout: lane (k = l>>5, j = l&31)
-//                  bilinearly samples channel-of-parity k for output pixel j.  Sampling coordinates, the four corner
-//                  weights and the mask are computed once per (pixel, group, tap) and reused by the group's channels
-//                  (the reference recomputes them per channel thread, dcn_v2_im2col_cuda.cu:137-175).  No column buffer,
-//                  no LDS, no barrier; bias added in the epilogue (the reference spends a rank-1 GEMM on it).
-//   backward data  dCol tile = W^T . gO on MFMA (gO kept in registers as the B operand), consumed in place: each lane owns
-//                  16 (k, pixel) entries and turns them into grad_mask / grad_offset partial sums and the grad_input
-//                  scatter (fp32 atomics), following dcn_v2_im2col_cuda.cu:56-123, 197-327.  All samples in one launch.
+//                  column matrix generated in registers, already in MFMA B-operand layout.  Sampling coordinates, the four
+//                  corner weights and the mask are computed once per (pixel, group, tap) and reused by the group's
+//                  channels (the reference recomputes them per channel thread, dcn_v2_im2col_cuda.cu:137-175).  No column
+//                  buffer; bias in the epilogue (the reference spends a rank-1 GEMM on it).
+//                  dcn_fwd_nhwc_kernel (8/16/32 channels per group, even group count): gathers from a zero-bordered
+//                  channels-last copy of the input (float4 per 4 channels, no validity logic), weights DMA'd to LDS in
+//                  chunks, two-deep gather pipeline, 8 x 4 pixel patch per wave; optional bf16-MFMA variant.
+//                  dcn_fwd_mfma_kernel: any other geometry, gathers from NCHW, weights from L1/L2.
+//   backward data  dCol tile = W^T . gO on MFMA (gO kept in registers as the B operand), consumed in place.
+//                  dcn_bwd_offmask_kernel (grad_input not requested): channels-last gathers, Wb tile in LDS, every lane
+//                  owns whole (tap, group)s of its pixel -> grad_offset / grad_mask are plain stores.
+//                  dcn_bwd_data_kernel (with grad_input): lanes turn their 16 (k, pixel) entries into grad_mask /
+//                  grad_offset partial sums and the grad_input scatter (fp32 atomics), dcn_v2_im2col_cuda.cu:56-123, 197-327.
+//                  All samples in one launch.
 //   backward weight grad_weight = gO . col^T with K = all pixels of the batch: tiles of gO and of the re-generated
 //                  columns are staged through LDS (lanes <-> pixels while gathering, lanes <-> rows as MFMA operands),
-//                  split-K over pixel ranges, fp32 atomics into grad_weight.
+//                  chunk n+1 fetched under the MFMAs of chunk n, split-K over pixel ranges, fp32 atomics into grad_weight.
 //
-// K order used on this path: k = (g * T + tap) * CPG + c_in_group  (T = kh*kw, CPG = C/dg); weights are re-laid out
-// once per call into that order (Wt[k][Co] for forward, Wb[o][k] for backward).
+// K orders: NCHW kernels k = (g * T + tap) * CPG + c_in_group (T = kh*kw, CPG = C/dg); channels-last forward
+// (tap, group, kk) with kk = 2t + hi <-> channel t + hi * CPG/2; offset/mask kernel: see weight_relayout_kernel.
+// Weights are re-laid out once per call (Wt[k][Co] forward, Wb[o][k] backward, Wh[k/8][Co][8] bf16).
 #include "c2m_common.h"
 
 namespace c2m {
