@@ -130,3 +130,23 @@ def test_optimizer_groups_follow_parameter_names():
     # 'offset' in name: {small,medium,large}_offset_conv{1,2} and *_dyn_agg.conv_offset_mask, weight+bias each
     assert n[1] == 6 and n[2] == 6 and n[3] == 6 and sum(n) == len(list(m.net_g.parameters()))
     assert "network_g" in opt and opt["network_g"]["type"] == "RestorationNet"  # caller's dict untouched
+
+
+def test_bench_flop_model_matches_kernel_tiling():
+    """bench.py prices the correlation kernel by the MFMA work it issues; the formula hard-codes the kernel's tiling
+    (14 x 14 query patches per workgroup, 28 ref patch columns per x-tile, 8 waves): keep the two in sync."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "c2-matching_amd", "csrc", "corr_argmax.hip")).read()
+    consts = {k: int(v) for k, v in re.findall(r"constexpr int (TQ|WT|WP|NWAVE) = (\d+);", src)}
+    assert consts == {"TQ": 16, "WT": 32, "WP": 28, "NWAVE": 8}
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, C, h = 16, 256, 160
+    tiles = (-(-(h - 2) // (consts["TQ"] - 2))) ** 2
+    steps = (-(-(h - 2) // consts["WP"])) * h
+    want = B * tiles * (steps + 1) * consts["NWAVE"] * (C // 2) * (2 * 32 * 32 * 2)
+    assert bench.corr_executed_flops(B, C, h) == want == 9286793035776
