@@ -71,6 +71,8 @@ def build_pre_offsets(max_idx, h, w, scales=(1, 2, 4)):
     B = mi.shape[0]
     if tuple(mi.shape[1:]) != (h - 2, w - 2):
         raise _lib.C2MError("max_idx must be [B, h-2, w-2]")
+    if not set(scales) <= {1, 2, 4} or len(set(scales)) != len(tuple(scales)):
+        raise _lib.C2MError(f"scales must be distinct members of (1, 2, 4), got {tuple(scales)}")
     outs = {s: torch.empty((B, 9, h * s, w * s, 2), dtype=torch.float32, device=mi.device) for s in scales}
     ptr = lambda s: outs[s].data_ptr() if s in outs else None  # noqa: E731
     with torch.cuda.device(mi.device):

@@ -90,14 +90,27 @@ class _OffsetMeanWatch:
     def __init__(self):
         self._pending = None
 
+    # the in-flight read-back (pinned buffer + event) is per-process scratch: modules stay picklable / deep-copyable
+    # (torch.save(net), copy.deepcopy(net), DataParallel replicas) like the reference's
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._pending = None
+
+    def __deepcopy__(self, memo):
+        return _OffsetMeanWatch()
+
     def poll(self):
-        if self._pending is not None:
-            host, event, numel = self._pending
+        pending = self._pending   # read once: DataParallel replicas share this object across threads
+        if pending is not None:
+            host, event, numel = pending
             if event.query():
                 mean = float(host.sum()) / numel
                 if mean > 100:
                     logger.warning('Offset mean is {}, larger than 100.'.format(mean))
-                self._pending = None
+                if self._pending is pending:
+                    self._pending = None
 
     def push(self, abs_sum, numel):
         if self._pending is None:
@@ -106,6 +119,21 @@ class _OffsetMeanWatch:
             event = torch.cuda.Event()
             event.record()
             self._pending = (host, event, numel)
+
+
+def _check_geometry(in_channels, out_channels, deformable_groups):
+    """The gfx950 kernels cover a subset of the geometries the reference's generic CUDA kernels accept; say so when the
+    module is built instead of at the first forward / backward (C2M_ERR_UNSUPPORTED)."""
+    if in_channels % deformable_groups != 0:
+        raise ValueError(f'in_channels ({in_channels}) must be divisible by deformable_groups ({deformable_groups})')
+    cpg = in_channels // deformable_groups
+    if cpg % 2 != 0:
+        raise NotImplementedError(f'DCNv2 on MI355X needs an even number of channels per deformable group, got '
+                                  f'{in_channels}/{deformable_groups} = {cpg}')
+    if cpg % 4 != 0 or out_channels > 256:
+        logger.warning(f'DCNv2({in_channels}, {out_channels}, deformable_groups={deformable_groups}): forward is '
+                       'supported, BACKWARD is not (needs channels-per-group % 4 == 0 and out_channels <= 256); '
+                       'training this layer will raise.')
 
 
 class DCNv2(nn.Module):
@@ -120,6 +148,7 @@ class DCNv2(nn.Module):
         self.padding = _pair(padding)
         self.dilation = _pair(dilation)
         self.deformable_groups = deformable_groups
+        _check_geometry(in_channels, out_channels, deformable_groups)
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.Tensor(out_channels))
         self.reset_parameters()

@@ -1,11 +1,18 @@
 """VGG feature taps with the reference's module/parameter naming (``vgg_arch.py:59-145``): ``vgg_net.conv1_1`` ...,
-buffers ``mean`` / ``std``.  torchvision is optional: when it is importable the ImageNet weights are loaded exactly as
-the reference does (``vgg_arch.py:104-105``); offline (no torchvision, no checkpoint download) the same layer stack is
-built locally with random weights -- benchmarks and parity tests overwrite them with seeded values anyway."""
+buffers ``mean`` / ``std``.  When torchvision is importable the ImageNet weights are loaded exactly as the reference
+does (``vgg_arch.py:104-105``); any failure of that load propagates, as in the reference.  Without torchvision the same
+layer stack is built locally and its weights come from ``$C2M_VGG_WEIGHTS/<vgg_type>.pth`` (a torchvision state dict);
+if that is absent too the weights are RANDOM and a warning says so loudly -- only synthetic benchmarks and parity tests,
+which overwrite them with seeded values, may run in that state."""
+import logging
+import os
+import warnings
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+
+logger = logging.getLogger('base')
 
 _CFG = {
     'vgg11': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
@@ -34,13 +41,28 @@ NAMES = {k: layer_names(k) for k in _CFG}
 def build_vgg_features(vgg_type, upto, pretrained=True):
     """OrderedDict name -> layer for layers [0, upto] of torchvision's vgg `features` stack."""
     names = NAMES[vgg_type][:upto + 1]
-    tv_layers = None
+    tv_layers, local_state = None, None
     if pretrained:
         try:
             import torchvision.models.vgg as tv_vgg
-            tv_layers = list(getattr(tv_vgg, vgg_type)(pretrained=True).features[:upto + 1])
-        except Exception:  # no torchvision / no network: local stack, caller loads weights from a checkpoint
-            tv_layers = None
+        except ImportError:
+            tv_vgg = None
+        if tv_vgg is not None:
+            # a failed download / changed torchvision API raises here, exactly as in the reference
+            enum = getattr(tv_vgg, f'{vgg_type.upper()}_Weights', None)
+            net = getattr(tv_vgg, vgg_type)(weights=enum.IMAGENET1K_V1) if enum is not None else \
+                getattr(tv_vgg, vgg_type)(pretrained=True)
+            tv_layers = list(net.features[:upto + 1])
+        else:
+            path = os.path.join(os.environ.get('C2M_VGG_WEIGHTS', ''), f'{vgg_type}.pth')
+            if os.environ.get('C2M_VGG_WEIGHTS') and os.path.exists(path):
+                local_state = torch.load(path, map_location='cpu')
+            else:
+                msg = (f'torchvision is not installed and $C2M_VGG_WEIGHTS/{vgg_type}.pth was not found: the {vgg_type} '
+                       'feature stack starts from RANDOM weights.  Load a checkpoint (or pass pretrained=False) before '
+                       'using it on real images.')
+                logger.warning(msg)
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
     out, c_in, pos = OrderedDict(), 3, 0
     for v in _CFG[vgg_type]:
         n_here = 1 if v == 'M' else 2
@@ -54,6 +76,11 @@ def build_vgg_features(vgg_type, upto, pretrained=True):
                 out[names[pos + 1]] = tv_layers[pos + 1] if tv_layers else nn.ReLU(inplace=True)
             c_in = v
         pos += n_here
+    if local_state is not None:   # torchvision key layout: features.<position>.{weight,bias}
+        for k, name in enumerate(names):
+            if isinstance(out[name], nn.Conv2d):
+                out[name].weight.data.copy_(local_state[f'features.{k}.weight'])
+                out[name].bias.data.copy_(local_state[f'features.{k}.bias'])
     return out
 
 

@@ -344,9 +344,20 @@ static void im2col_sample(const dcn_geom* g, const float* in, const float* off, 
 }
 
 /* dcn_v2_cuda_forward, dcn_v2_cuda.cu:42-172: out[b] = bias (rank-1 GEMM :123-137) + W[Co x CK] . col[b] (:149-163) */
-int c2m_oracle_dcn_v2_forward(const float* in, const float* weight, const float* bias, const float* offset,
-                              const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
-                              int ph, int pw, int dh, int dw, int dg, float* out) {
+/* round-to-nearest-even to bfloat16 (8 significand bits), result widened back to float */
+static float round_bf16(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return v; /* NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&v, &u, 4);
+  return v;
+}
+
+static int dcn_forward_impl(const float* in, const float* weight, const float* bias, const float* offset,
+                            const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                            int ph, int pw, int dh, int dw, int dg, float* out, int bf16_cols) {
   dcn_geom g;
   if (!in || !weight || !bias || !offset || !mask || !out) return C2M_EINVAL;
   int rc = dcn_geom_init(&g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg);
@@ -357,6 +368,8 @@ int c2m_oracle_dcn_v2_forward(const float* in, const float* weight, const float*
   for (int b = 0; b < B; ++b) {
     im2col_sample(&g, in + (size_t)b * C * H * W, offset + (size_t)b * dg * 2 * K * HWo,
                   mask + (size_t)b * dg * K * HWo, col);
+    if (bf16_cols)
+      for (size_t e = 0; e < (size_t)CK * HWo; ++e) col[e] = round_bf16(col[e]);
     float* ob = out + (size_t)b * Co * HWo;
 #pragma omp parallel for schedule(static)
     for (int o = 0; o < Co; ++o) {
@@ -373,6 +386,22 @@ int c2m_oracle_dcn_v2_forward(const float* in, const float* weight, const float*
   }
   free(col);
   return C2M_OK;
+}
+
+int c2m_oracle_dcn_v2_forward(const float* in, const float* weight, const float* bias, const float* offset,
+                              const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw,
+                              int ph, int pw, int dh, int dw, int dg, float* out) {
+  return dcn_forward_impl(in, weight, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, out, 0);
+}
+
+/* Checker for the bf16-MFMA variant of the HIP forward (c2m_dcn_v2_forward_bf16mma_f32; the reference has no reduced-
+ * precision path): the same operator with the column matrix rounded to bfloat16 before the fp32-accumulated product.
+ * The caller hands over `in` and `weight` already rounded to bfloat16 (what the kernel's staging copy / weight re-layout
+ * hold); sampling positions, bilinear weights, mask and bias stay float32. */
+int c2m_oracle_dcn_v2_forward_bf16cols(const float* in, const float* weight, const float* bias, const float* offset,
+                                       const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh,
+                                       int sw, int ph, int pw, int dh, int dw, int dg, float* out) {
+  return dcn_forward_impl(in, weight, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, out, 1);
 }
 
 /* dcn_v2_cuda_backward, dcn_v2_cuda.cu:206-335 (per-sample loop :259-330).  All grads are OVERWRITTEN

@@ -36,6 +36,7 @@ def lib():
         L.c2m_oracle_feature_match_index.argtypes = [_f32p, _f32p] + [_int] * 12 + [_i64p, _f32p]
         L.c2m_oracle_build_pre_offsets.argtypes = [_i64p, _int, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.c2m_oracle_dcn_v2_forward.argtypes = [_f32p] * 5 + [_int] * 14 + [_f32p]
+        L.c2m_oracle_dcn_v2_forward_bf16cols.argtypes = [_f32p] * 5 + [_int] * 14 + [_f32p]
         L.c2m_oracle_dcn_v2_backward.argtypes = [_f32p] * 6 + [_int] * 14 + [_f32p] * 5
         L.c2m_oracle_set_num_threads.argtypes = [_int]
         _lib = L
@@ -120,6 +121,26 @@ def dcn_v2_forward(inp, weight, bias, offset, mask, stride=(1, 1), padding=(1, 1
     g, ho, wo = _geom(inp, weight, stride, padding, dilation)
     out = np.empty((g[0], g[4], ho, wo), np.float32)
     _chk(lib().c2m_oracle_dcn_v2_forward(inp, weight, bias, offset, mask, *g, deformable_groups, out), "dcn_v2_forward")
+    return out
+
+
+def round_bf16(a):
+    """float32 array rounded (RNE) to bfloat16 precision, returned as float32."""
+    u = _f32(a).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def dcn_v2_forward_bf16(inp, weight, bias, offset, mask, stride=(1, 1), padding=(1, 1), dilation=(1, 1),
+                        deformable_groups=1):
+    """Checker of the bf16-MFMA forward: input, weights and the blended+masked column values rounded to bfloat16, fp32
+    accumulation; positions / bilinear weights / mask / bias float32."""
+    inp, weight = round_bf16(inp), round_bf16(weight)
+    bias, offset, mask = map(_f32, (bias, offset, mask))
+    g, ho, wo = _geom(inp, weight, stride, padding, dilation)
+    out = np.empty((g[0], g[4], ho, wo), np.float32)
+    _chk(lib().c2m_oracle_dcn_v2_forward_bf16cols(inp, weight, bias, offset, mask, *g, deformable_groups, out),
+         "dcn_v2_forward_bf16cols")
     return out
 
 

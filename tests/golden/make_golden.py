@@ -6,7 +6,7 @@ Runs only in the build container (needs /root/reference).  Nothing of the refere
 installed here (mmcv.scandir, torchvision's VGG layer layout) -- `corres_generation_arch.py`, runs them on CPU and
 stores inputs' seeds + the outputs.  The fixtures are data (arrays), committed next to this script.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [small|full160|cfg5|metrics|all]     (default: small = the round-1 fixtures)
 """
 import importlib.util
 import os
@@ -151,6 +151,115 @@ def restoration_inputs(B, h, w):
     return lr, pre, feats
 
 
+def full160_inputs(b):
+    """Pair b of the BASELINE configs[1]/[2] shape: 256 x 160 x 160 normalised features; the ref map carries the constant
+    band a zero-padded 500x500 Ref leaves beyond 125/160 (ref_cufed_dataset.py:107-114) and a block of queries matches
+    that band exactly (thousands of exactly-equal maxima).  At this size the reference runs its TWO-chunk path
+    (batch_size = int(1024**2 * 512 / (160*160)) = 20971 < 24964 patches, ref_map_util.py:54-76)."""
+    C, h = 256, 160
+    fi = oracle.feature_normalize(synth.gaussish((C, h, h), 91 + 10 * b))
+    raw = synth.gaussish((C, h, h), 92 + 10 * b)
+    raw[:, 125:, :] = raw[:, 125:126, 125:126]
+    raw[:, :, 125:] = raw[:, 125:126, 125:126]
+    fr = oracle.feature_normalize(raw)
+    fi[:, 150:, 150:] = fr[:, 130:131, 130:131]
+    return np.ascontiguousarray(fi), np.ascontiguousarray(fr)
+
+
+FULL160_PAIRS = 16
+
+
+def make_full160():
+    """Reference index maps (uint16: Nr = 24964 < 65536) of 16 distinct full-size pairs + values of pair 0."""
+    rmu = load_ref_map_util()
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for b in range(FULL160_PAIRS):
+        fi, fr = full160_inputs(b)
+        idx, val = rmu.feature_match_index(torch.from_numpy(fi), torch.from_numpy(fr), patch_size=3, input_stride=1,
+                                           ref_stride=1, is_norm=True, norm_input=True)
+        assert int(idx.max()) < 65536
+        out[f"idx{b}"] = idx.numpy().astype(np.uint16)
+        if b == 0:
+            out["val0"] = val.numpy().astype(np.float32)
+        print("full160 pair", b, "idx range", int(idx.min()), int(idx.max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "corr_full160_golden.npz"), **out)
+
+
+CFG5_ROWS = ((0, 6), (157, 163), (314, 320))   # query pixel-row slices (each gives 4 query patch rows)
+
+
+def cfg5_inputs():
+    """BASELINE configs[4] shape: 256 x 320 x 320 features, 500x500 Ref zero-padded to 1280x1280 -> valid 125/320."""
+    C, h = 256, 320
+    fi = oracle.feature_normalize(synth.gaussish((C, h, h), 591))
+    raw = synth.gaussish((C, h, h), 592)
+    raw[:, 125:, :] = raw[:, 125:126, 125:126]
+    raw[:, :, 125:] = raw[:, 125:126, 125:126]
+    fr = oracle.feature_normalize(raw)
+    fi[:, 316:, 300:] = fr[:, 200:201, 200:201]
+    return np.ascontiguousarray(fi), np.ascontiguousarray(fr)
+
+
+def make_cfg5():
+    """Reference index maps for three slices of query rows at the configs[4] feature size (Nq = Nr = 101124): the
+    reference function run on feat_input[:, r0:r1] against the FULL ref map (one row slice costs ~1/50 of the pair)."""
+    rmu = load_ref_map_util()
+    torch.set_num_threads(os.cpu_count())
+    fi, fr = cfg5_inputs()
+    out = {}
+    for (r0, r1) in CFG5_ROWS:
+        idx, val = rmu.feature_match_index(torch.from_numpy(np.ascontiguousarray(fi[:, r0:r1])), torch.from_numpy(fr),
+                                           patch_size=3, input_stride=1, ref_stride=1, is_norm=True, norm_input=True)
+        out[f"idx_{r0}"] = idx.numpy().astype(np.int64)
+        out[f"val_{r0}"] = val.numpy().astype(np.float32)
+        print("cfg5 rows", r0, r1, "idx range", int(idx.min()), int(idx.max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "corr_cfg5_golden.npz"), **out)
+
+
+def metric_images(k):
+    """Two float images in the layout tensor2img produces (H x W x 3, BGR, integer-valued floats in [0, 255])."""
+    a = np.round(synth.uniform((37 + k, 41, 3), 7000 + k, 0.0, 255.0)).astype(np.float32)
+    noise = synth.gaussish((37 + k, 41, 3), 7100 + k) * (2.0 + 3.0 * k)
+    b = np.clip(np.round(a + noise), 0, 255).astype(np.float32)
+    return a, b
+
+
+def make_metrics():
+    """PSNR / PSNR_Y / SSIM_Y of the reference's mmsr/utils/metrics.py (psnr :34-66, ssim :69-143, bgr2ycbcr :146-168) on
+    synthetic image pairs, computed exactly as nondist_validation does (ref_restoration_model.py:338-351).  cv2 is absent
+    here: `filter2D(img, -1, window)[5:-5, 5:-5]` -- the only cv2 call whose result is used away from the image border --
+    is stood in for by scipy's correlate (the 11x11 Gaussian window is symmetric; the crop removes every border pixel)."""
+    import scipy.ndimage
+    cv2 = types.ModuleType("cv2")
+
+    def gk(n, sigma):
+        x = np.arange(n, dtype=np.float64) - (n - 1) / 2
+        k = np.exp(-(x * x) / (2 * sigma * sigma))
+        return (k / k.sum()).reshape(n, 1)
+    cv2.getGaussianKernel = gk
+
+    def filter2d(img, ddepth, window):   # the reference hands over (H, W, 1) arrays after its crop (metrics.py:135-136)
+        flat = img.reshape(img.shape[0], img.shape[1])
+        return scipy.ndimage.correlate(flat, window, mode="reflect").reshape(img.shape)
+    cv2.filter2D = filter2d
+    sys.modules["cv2"] = cv2
+    spec = importlib.util.spec_from_file_location("metrics_reference", f"{REF}/mmsr/utils/metrics.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = {}
+    for k in range(3):
+        a, b = metric_images(k)
+        crop = 4
+        out[f"psnr{k}"] = np.float64(m.psnr(a.copy(), b.copy(), crop_border=crop))
+        ay = m.bgr2ycbcr(a.copy() / 255., only_y=True)
+        by = m.bgr2ycbcr(b.copy() / 255., only_y=True)
+        out[f"psnr_y{k}"] = np.float64(m.psnr(ay * 255, by * 255, crop_border=crop))
+        out[f"ssim_y{k}"] = np.float64(m.ssim(ay * 255, by * 255, crop_border=crop))
+        print("metrics", k, out[f"psnr{k}"], out[f"psnr_y{k}"], out[f"ssim_y{k}"])
+    np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -219,4 +328,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what in ("small", "all"):
+        main()
+    if what in ("full160", "all"):
+        make_full160()
+    if what in ("cfg5", "all"):
+        make_cfg5()
+    if what in ("metrics", "all"):
+        make_metrics()

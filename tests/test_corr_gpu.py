@@ -137,6 +137,50 @@ def test_full_size_160_properties(env, dev):
     assert idx.min() >= 0 and idx.max() < 158 * 158
 
 
+def test_full_size_160_batch16_whole_maps_vs_reference_and_oracle(env, dev, golden_dir):
+    """BASELINE configs[1]: ONE launch over a batch of 16 distinct 160x160x256 pairs.  Every whole index map equals the
+    map the reference's own Python produced for that pair (tests/golden/corr_full160_golden.npz: its two-chunk path with
+    the strict-> merge, constant-band ties); pairs 0 and 15 additionally equal the oracle on ALL rows, indices and values
+    bitwise."""
+    ops, oracle, _ = env
+    from make_golden import FULL160_PAIRS, full160_inputs
+    g = np.load(f"{golden_dir}/corr_full160_golden.npz")
+    pairs = [full160_inputs(b) for b in range(FULL160_PAIRS)]
+    fi = torch.stack([torch.from_numpy(p[0]) for p in pairs]).to(dev)
+    fr = torch.stack([torch.from_numpy(p[1]) for p in pairs]).to(dev)
+    idx, val = ops.feature_match_index_batched(fi, fr, 3, 1, 1, True, True)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    for b in range(FULL160_PAIRS):
+        assert np.array_equal(idx[b], g[f"idx{b}"].astype(np.int64)), f"pair {b}: HIP index map != reference golden"
+    np.testing.assert_allclose(val[0], g["val0"], rtol=0, atol=2e-6)
+    for b in (0, FULL160_PAIRS - 1):
+        oi, ov = oracle.feature_match_index(pairs[b][0], pairs[b][1], 3, 1, 1, True, True)
+        assert np.array_equal(idx[b], oi) and np.array_equal(val[b], ov), f"pair {b}: HIP != oracle (bitwise)"
+
+
+def test_cfg5_320_vs_reference_rows_and_oracle(env, dev, golden_dir):
+    """BASELINE configs[4] feature size (320x320x256, Nq = Nr = 101124, the largest map any config asks for): the MFMA
+    kernel equals the generic kernel bitwise on the whole map, the reference's output on three slices of query rows
+    (golden) and the oracle bitwise on those rows."""
+    ops, oracle, _ = env
+    from make_golden import CFG5_ROWS, cfg5_inputs
+    g = np.load(f"{golden_dir}/corr_cfg5_golden.npz")
+    fi, fr = cfg5_inputs()
+    ti, tr = _t(fi[None], dev), _t(fr[None], dev)
+    idx, val = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True)
+    gidx, gval = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True, force_generic=True)
+    assert torch.equal(idx, gidx) and torch.equal(val, gval)
+    idx, val = idx[0].cpu().numpy(), val[0].cpu().numpy()
+    assert idx.shape == (318, 318) and idx.min() >= 0 and idx.max() < 318 * 318
+    for (r0, r1) in CFG5_ROWS:
+        assert np.array_equal(idx[r0:r1 - 2], g[f"idx_{r0}"]), f"rows {r0}: HIP index map != reference golden"
+        np.testing.assert_allclose(val[r0:r1 - 2], g[f"val_{r0}"], rtol=0, atol=4e-6)   # oneDNN vs canonical order; values ~1
+        oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=(r0, r1 - 2))
+        assert np.array_equal(idx[r0:r1 - 2], oi[r0:r1 - 2]) and np.array_equal(val[r0:r1 - 2], ov[r0:r1 - 2])
+    # queries inside the constant band tie on every fully-constant ref patch: the lowest such index is (0, 125)
+    assert (idx[316:, 300:] == 125).all()
+
+
 def test_pre_offsets_bit_exact(env, dev, golden_dir):
     ops, oracle, synth = env
     g = np.load(f"{golden_dir}/pre_offset_golden.npz")
@@ -164,6 +208,8 @@ def test_errors_are_loud(env, dev):
         ops.feature_match_index_batched(torch.zeros(1, 4, 2, 8, device=dev), torch.zeros(1, 4, 8, 8, device=dev))
     with pytest.raises(c2m_amd.C2MError):
         ops.feature_normalize(torch.zeros(1, 4, 8, 8, device=dev, dtype=torch.float64))
+    with pytest.raises(c2m_amd.C2MError):   # only scales 1, 2, 4 exist: anything else used to return uninitialised memory
+        ops.build_pre_offsets(torch.zeros((1, 6, 6), dtype=torch.int64, device=dev), 8, 8, scales=(1, 3))
 
 
 def test_mmsr_ref_map_util_signature(env, dev):

@@ -61,20 +61,26 @@ def test_forward_matches_oracle(env, dev, shape):
 
 
 @pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[7]])
-def test_forward_bf16_mma_close_to_fp32(env, dev, shape):
-    """bf16-MFMA variant (fp32 tensors, weights and blended samples rounded to bf16, fp32 accumulation): must equal the
-    oracle evaluated on bf16-rounded weights up to the rounding of the column values -- i.e. stay within a few bf16 ulps
-    of the fp32 result in the 2-norm, and be exactly the fp32 operator when everything is bf16-representable."""
+def test_forward_bf16_mma_matches_bf16_oracle(env, dev, shape):
+    """bf16-MFMA variant (fp32 tensors; staged input, weights and blended samples rounded to bf16, fp32 accumulation)
+    against the ORACLE evaluated with exactly those roundings (oracle.dcn_v2_forward_bf16).  The only freedom left is the
+    fp32 rounding of a column value before it is rounded to bf16 (mask folded into the bilinear weights here, applied
+    after the blend there): rare 1-bf16-ulp flips of single column entries.  Measured ~3e-5 relative in the 2-norm, i.e.
+    200x below the distance to the fp32 operator (~6e-3), which is also bounded."""
     ops, oracle, synth = env
     B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
     x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 300)
     args = [_t(a, dev) for a in (x, w, b, off, msk)]
-    ref = ops.dcn_v2_forward(*args, st, pd, dl, dg)
-    got = ops.dcn_v2_forward(*args, st, pd, dl, dg, bf16_mma=True)
-    rel = float((got - ref).norm() / ref.norm())
-    assert rel < 6e-3, f"bf16 MFMA forward deviates {rel} (2-norm, relative) from fp32"
-    assert rel > 0 or C // dg < 8   # it really ran the reduced-precision kernel (except where only fp32 kernels exist)
-    # integer-valued data (exactly representable in bf16, integer sample positions): identical to fp32
+    got = ops.dcn_v2_forward(*args, st, pd, dl, dg, bf16_mma=True).cpu().numpy()
+    want16 = oracle.dcn_v2_forward_bf16(x, w, b, off, msk, st, pd, dl, dg)
+    want32 = oracle.dcn_v2_forward(x, w, b, off, msk, st, pd, dl, dg)
+    rel16 = float(np.linalg.norm(got - want16) / np.linalg.norm(want16))
+    rel32 = float(np.linalg.norm(got - want32) / np.linalg.norm(want32))
+    assert rel16 < 3e-4, f"bf16 MFMA forward vs bf16 oracle: {rel16}"
+    assert float(np.abs(got - want16).max()) < 2e-3 * max(1.0, float(np.abs(want16).max()))
+    assert rel32 < 6e-3, f"bf16 MFMA forward deviates {rel32} (2-norm, relative) from the fp32 oracle"
+    assert rel32 > 3 * rel16   # it really ran the reduced-precision kernel and the bf16 oracle really models it
+    # integer-valued data (exactly representable in bf16, integer sample positions): identical to the fp32 operator
     xi = torch.round(args[0] * 2).clamp(-8, 8)
     wi = torch.round(args[1] * 64).clamp(-4, 4)
     offi = torch.round(args[3])
@@ -82,6 +88,9 @@ def test_forward_bf16_mma_close_to_fp32(env, dev, shape):
     a = ops.dcn_v2_forward(xi, wi, args[2], offi, mski, st, pd, dl, dg)
     c = ops.dcn_v2_forward(xi, wi, args[2], offi, mski, st, pd, dl, dg, bf16_mma=True)
     assert torch.equal(a, c)
+    np.testing.assert_allclose(a.cpu().numpy(), oracle.dcn_v2_forward(xi.cpu().numpy(), wi.cpu().numpy(), b,
+                                                                     offi.cpu().numpy(), mski.cpu().numpy(), st, pd, dl, dg),
+                               rtol=0, atol=2e-5 * max(1.0, float(a.abs().max())))
 
 
 def test_forward_zero_offset_is_conv2d(env, dev):

@@ -150,3 +150,42 @@ def test_bench_flop_model_matches_kernel_tiling():
     steps = (-(-(h - 2) // consts["WP"])) * h
     want = B * tiles * (steps + 1) * consts["NWAVE"] * (C // 2) * (2 * 32 * 32 * 2)
     assert bench.corr_executed_flops(B, C, h) == want == 9286793035776
+
+
+def test_dcn_modules_are_copyable_and_picklable():
+    """the deferred offset-mean watch must not make copy.deepcopy(net) / torch.save(net) fail."""
+    import copy
+    import io
+    import torch
+    from mmsr.models.archs.DCNv2.dcn_v2 import DCN_sep_pre_multi_offset, _OffsetMeanWatch
+    m = DCN_sep_pre_multi_offset(16, 16, 3, stride=1, padding=1, deformable_groups=2)
+    m._watch._pending = (object(), object(), 1)   # as after a forward: un-picklable scratch
+    c = copy.deepcopy(m)
+    assert isinstance(c._watch, _OffsetMeanWatch) and c._watch._pending is None and c._watch is not m._watch
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._watch._pending is None and torch.equal(r.weight, m.weight)
+
+
+def test_dcn_geometry_is_validated_at_construction():
+    import pytest
+    from mmsr.models.archs.DCNv2.dcn_v2 import DCNv2
+    with pytest.raises(NotImplementedError):
+        DCNv2(9, 8, 3, 1, 1, deformable_groups=3)     # 3 channels per group: no kernel
+    with pytest.raises(ValueError):
+        DCNv2(10, 8, 3, 1, 1, deformable_groups=3)
+    DCNv2(12, 8, 3, 1, 1, deformable_groups=2)        # 6 per group: forward only (warning), constructs
+
+
+def test_vgg_without_torchvision_says_weights_are_random(monkeypatch):
+    """never fall back to random VGG weights silently."""
+    import importlib.util
+    import pytest
+    if importlib.util.find_spec('torchvision') is not None:
+        pytest.skip('torchvision present: the ImageNet weights are loaded as in the reference')
+    monkeypatch.delenv('C2M_VGG_WEIGHTS', raising=False)
+    from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
+    with pytest.warns(RuntimeWarning, match='RANDOM weights'):
+        VGGFeatureExtractor(['relu1_1'], 'vgg19')

@@ -59,3 +59,25 @@ def test_pre_offsets_match_reference(golden_dir):
         idx, _ = oracle.feature_match_index(oracle.feature_normalize(f1[b]), oracle.feature_normalize(f2[b]), 3, 1, 1, True, True)
         o3, o2, o1 = oracle.build_pre_offsets(idx, h, w)
         assert np.array_equal(o3, g["relu3_1"][b]) and np.array_equal(o2, g["relu2_1"][b]) and np.array_equal(o1, g["relu1_1"][b])
+
+
+def test_full_size_160_pair_matches_reference(golden_dir):
+    """BASELINE configs[1]/[2] size: the whole 158x158 index map of pair 0 against the reference's output (its two-chunk
+    path with the strict-> merge, ref_map_util.py:54-76; constant band -> thousands of exact ties)."""
+    from make_golden import full160_inputs
+    g = np.load(f"{golden_dir}/corr_full160_golden.npz")
+    fi, fr = full160_inputs(0)
+    idx, val = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
+    assert np.array_equal(idx, g["idx0"].astype(np.int64))
+    np.testing.assert_allclose(val, g["val0"], rtol=0, atol=2e-6)
+
+
+def test_cfg5_row_slices_match_reference(golden_dir):
+    """BASELINE configs[4] feature size (320x320, Nq = Nr = 101124): three slices of query rows against the reference."""
+    from make_golden import CFG5_ROWS, cfg5_inputs
+    g = np.load(f"{golden_dir}/corr_cfg5_golden.npz")
+    fi, fr = cfg5_inputs()
+    for (r0, r1) in CFG5_ROWS:
+        idx, val = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=(r0, r1 - 2))
+        assert np.array_equal(idx[r0:r1 - 2], g[f"idx_{r0}"])
+        np.testing.assert_allclose(val[r0:r1 - 2], g[f"val_{r0}"], rtol=0, atol=4e-6)   # oneDNN vs canonical order; values ~1

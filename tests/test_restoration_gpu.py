@@ -81,15 +81,17 @@ def test_full_chain_config1_matches_cpu_chain_built_from_oracle_ops(dev):
 
 
 def test_full_chain_under_bf16_autocast(dev):
-    """BASELINE config 5 runs inference under bf16 autocast.  The plain convolutions then compute in bf16; the hot path
-    takes their outputs as float32 (custom_fwd(cast_inputs=float32) / .float()) and the SR image must stay close to the
-    fp32 one: PSNR of the difference far above the 0.02 dB budget the config allows on a ~30 dB restoration."""
+    """bf16 autocast at configs[0] size: the plain convolutions compute in bf16; the hot path takes their outputs as
+    float32 (custom_fwd(cast_inputs=float32) / .float()).  PSNR against a synthetic ground truth, computed with the
+    reference's validation rules, stays within the 0.02 dB budget BASELINE configs[4] states (the full-size version of this
+    test is test_cfg5_320_bf16_autocast_psnr_budget)."""
+    from mmsr.utils import metrics
     ext, mp, g = _build_chain(dev)
-    gen = torch.Generator(device=dev).manual_seed(5)
-    lq = torch.rand((1, 3, 40, 40), generator=gen, device=dev)
-    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False)
+    gt = _smooth_gt(1, 160, 5).to(dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
     ref = torch.zeros((1, 3, 160, 160), device=dev)
-    ref[:, :, :64, :64] = torch.rand((1, 3, 64, 64), generator=gen, device=dev)
+    ref[:, :, :64, :64] = _smooth_gt(1, 64, 6).to(dev)
 
     def run():
         feats = ext(up, ref)
@@ -101,8 +103,9 @@ def test_full_chain_under_bf16_autocast(dev):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             sr16 = run()
     assert torch.isfinite(sr16).all()
-    mse = float(((sr16.float() - sr32) ** 2).mean())
-    assert mse < 1e-3, f"bf16-autocast SR deviates from fp32: mse {mse}"   # >= 30 dB on a [0, 1] signal
+    p32 = float(metrics.validation_metrics(sr32, gt, 4)["psnr"][0])
+    p16 = float(metrics.validation_metrics(sr16.float(), gt, 4)["psnr"][0])
+    assert 15.0 < p32 < 60.0 and abs(p16 - p32) <= 0.02, (p32, p16)
 
 
 def test_stage3_training_step_runs_and_learns(dev):
@@ -138,3 +141,203 @@ def test_stage3_training_step_runs_and_learns(dev):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     out = model.test()
     assert tuple(out.shape) == (B, 3, 4 * h, 4 * h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE-size chains (configs[2], [3], [4]).  The DynAgg sites are checked against the oracle through MODULE-level
+# hooks (inputs [ref_feat, offset_feat] + pre_offset -> output), so the checks do not depend on how the operator is
+# fused internally: the expected value is conv_offset_mask (torch fp64 on the CPU) -> the offset/mask assembly of
+# dcn_v2.py:229-245 in numpy -> oracle.dcn_v2_forward.
+# ---------------------------------------------------------------------------------------------------------------------
+def _dynagg_expected(oracle, module, ref_feat, offset_feat, pre_offset, b):
+    """Oracle value of one DynAgg call for sample b: (out [Co,H,W], offset, mask)."""
+    dg, K = module.deformable_groups, 9
+    head = module.conv_offset_mask
+    raw = torch.nn.functional.conv2d(offset_feat[b:b + 1].double().cpu(), head.weight.double().cpu(),
+                                     head.bias.double().cpu(), padding=1)[0].float().numpy()
+    o1, o2, m = raw[:dg * K], raw[dg * K:2 * dg * K], raw[2 * dg * K:]
+    offset = np.concatenate([o1, o2], 0)                                   # [2*dg*K, H, W]
+    pre = pre_offset[b].cpu().numpy()                                      # [9, H, W, 2] (x, y)
+    pre_yx = np.stack([pre[..., 1], pre[..., 0]], 1).reshape(2 * K, *pre.shape[1:3])   # (y, x) interleaved per tap
+    offset = offset + np.tile(pre_yx, (dg, 1, 1))
+    mask = 1.0 / (1.0 + np.exp(-m.astype(np.float64)))
+    want = oracle.dcn_v2_forward(ref_feat[b:b + 1].cpu().numpy(), module.weight.detach().cpu().numpy(),
+                                 module.bias.detach().cpu().numpy(), offset[None], mask[None].astype(np.float32),
+                                 (1, 1), (1, 1), (1, 1), dg)[0]
+    return want, offset, mask.astype(np.float32)
+
+
+def _hook_dynagg(net, store, keep_grad=False):
+    for stage in ("small", "medium", "large"):
+        mod = getattr(net.dyn_agg_restore, f"{stage}_dyn_agg")
+
+        def hook(m, args, out, stage=stage):
+            (x, pre) = args
+            store[stage] = {"ref": x[0].detach(), "feat": x[1].detach(), "pre": pre.detach() if torch.is_tensor(pre) else pre,
+                            "out": out.detach()}
+            if keep_grad and out.requires_grad:
+                out.register_hook(lambda g, stage=stage: store[stage].__setitem__("gout", g.detach()))
+        mod.register_forward_hook(hook)
+
+
+def _synthetic_pairs(B, h, dev, seed):
+    """configs[2]-[4] style inputs: LR h x h, bicubic x4 upsampled LR, a 500x500 Ref zero-padded to the 4h canvas
+    (test-time rule of ref_cufed_dataset.py:107-114; for h = 40 the Ref is 64x64 as in configs[0])."""
+    import synth
+    lq = torch.from_numpy(synth.uniform((B, 3, h, h), seed, 0.0, 1.0))
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    v = min(500, 4 * h) if h >= 125 else 64
+    ref = np.zeros((B, 3, 4 * h, 4 * h), np.float32)
+    ref[:, :, :v, :v] = synth.uniform((B, 3, v, v), seed + 1, 0.0, 1.0)
+    return lq.to(dev), up.to(dev), torch.from_numpy(ref).to(dev)
+
+
+def test_cfg3_chain_160_batch2(dev):
+    """BASELINE configs[2] shape at B=2: extractor -> correlation/index map -> pre-offsets -> VGG taps -> RestorationNet at
+    LR 160x160 / Ref 500x500 padded to 640x640.  Sample 1 (not 0: batch indexing) is checked against the oracle: index
+    map on row slices (bit-exact), pre-offset maps at all three scales (bit-exact), the three DynAgg outputs at
+    160/320/640 (1e-4 * scale), SR finite and batch-independent."""
+    import c2m_oracle as oracle
+    ext, mp, g = _build_chain(dev)
+    lq, up, ref = _synthetic_pairs(2, 160, dev, 4000)
+    taps = {}
+    _hook_dynagg(g, taps)
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        sr = g(lq, pre, ref_feat)
+        idx, _ = mp.match(feats)
+    assert tuple(sr.shape) == (2, 3, 640, 640) and bool(torch.isfinite(sr).all())
+    b = 1
+    f1 = oracle.feature_normalize(feats["dense_features1"][b].cpu().numpy())
+    f2 = oracle.feature_normalize(feats["dense_features2"][b].cpu().numpy())
+    hidx = idx[b].cpu().numpy()
+    for rows in ((0, 3), (77, 80), (155, 158)):
+        oi, _ = oracle.feature_match_index(f1, f2, 3, 1, 1, True, True, qrows=rows)
+        assert np.array_equal(hidx[rows[0]:rows[1]], oi[rows[0]:rows[1]])
+    o3, o2, o1 = oracle.build_pre_offsets(hidx, 160, 160)
+    assert np.array_equal(pre["relu3_1"][b].cpu().numpy(), o3)
+    assert np.array_equal(pre["relu2_1"][b].cpu().numpy(), o2)
+    assert np.array_equal(pre["relu1_1"][b].cpu().numpy(), o1)
+    for stage in ("small", "medium", "large"):
+        t = taps[stage]
+        mod = getattr(g.dyn_agg_restore, f"{stage}_dyn_agg")
+        want, _, _ = _dynagg_expected(oracle, mod, t["ref"], t["feat"], t["pre"], b)
+        got = t["out"][b].cpu().numpy()
+        err = float(np.abs(got - want).max())
+        assert err < 1e-4 * max(1.0, float(np.abs(want).max())), f"DynAgg {stage} at LR 160: {err}"
+    # samples of a batch are independent: sample 1 alone gives the same SR image
+    with torch.no_grad():
+        feats1 = ext(up[1:], ref[1:])
+        pre1, ref_feat1 = mp(feats1, ref[1:])
+        sr1 = g(lq[1:], pre1, ref_feat1)
+    assert float((sr1[0] - sr[1]).abs().max()) < 1e-3   # north_star's bound; conv algorithms may differ with B
+
+
+def test_cfg4_per_rank_training_step(dev):
+    """BASELINE configs[3], the slice one rank runs: 4 pairs, GT 160x160 -> LR 40x40, Ref 160x160, n_blocks=16, L1 loss,
+    the reference's four Adam groups.  The DCNv2 weight / bias gradients of the three DynAgg layers equal the oracle's
+    backward on the tensors captured at the module boundary (1e-4 * scale); every parameter gets a gradient; the loss goes
+    down."""
+    import c2m_oracle as oracle
+    import synth
+    from mmsr.models.ref_restoration_model import RefRestorationModel
+    opt = {"dist": False, "gpu_ids": [0], "is_train": True, "path": {},
+           "network_g": {"type": "RestorationNet", "ngf": 64, "n_blocks": 16, "groups": 8},
+           "network_map": {"type": "CorrespondenceGenerationArch", "patch_size": 3, "stride": 1,
+                           "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
+           "network_extractor": {"type": "ContrasExtractorSep"},
+           "train": {"lr_g": 1e-4, "lr_offset": 1e-4, "lr_relu2_offset": 1e-5, "lr_relu3_offset": 1e-6,
+                     "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0}}
+    torch.manual_seed(11)
+    model = RefRestorationModel(opt)
+    _fill(model.net_g, "net_g.")
+    B, h = 4, 40
+    gt = torch.from_numpy(synth.uniform((B, 3, 4 * h, 4 * h), 5000, 0.0, 1.0))
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    ref = torch.from_numpy(synth.uniform((B, 3, 4 * h, 4 * h), 5001, 0.0, 1.0))
+    model.feed_data({"img_in_lq": lq, "img_ref": ref, "img_in": gt, "img_in_up": up})
+    taps = {}
+    _hook_dynagg(model.net_g, taps, keep_grad=True)
+    # one forward/backward by hand (same calls as optimize_parameters, without the optimiser step) for the gradient check
+    model._correspondence()
+    out = model.net_g(model.img_in_lq, model.pre_offset, model.img_ref_feat)
+    loss = model.cri_pix(out, model.gt)
+    model.optimizer_g.zero_grad()
+    loss.backward()
+    missing = [n for n, p in model.net_g.named_parameters() if p.grad is None]
+    assert not missing, missing
+    for stage in ("small", "medium", "large"):
+        t = taps[stage]
+        mod = getattr(model.net_g.dyn_agg_restore, f"{stage}_dyn_agg")
+        gw = np.zeros(tuple(mod.weight.shape), np.float32)
+        gb = np.zeros(tuple(mod.bias.shape), np.float32)
+        for b in range(B):
+            _, offset, mask = _dynagg_expected(oracle, mod, t["ref"], t["feat"], t["pre"], b)
+            g = oracle.dcn_v2_backward(t["ref"][b:b + 1].cpu().numpy(), mod.weight.detach().cpu().numpy(),
+                                       mod.bias.detach().cpu().numpy(), offset[None], mask[None],
+                                       t["gout"][b:b + 1].cpu().numpy(), (1, 1), (1, 1), (1, 1), mod.deformable_groups)
+            gw += g[3]
+            gb += g[4]
+        for name, got, want in (("weight", mod.weight.grad, gw), ("bias", mod.bias.grad, gb)):
+            err = float(np.abs(got.cpu().numpy() - want).max())
+            assert err < 1e-4 * max(float(np.abs(want).max()), 1e-6) + 1e-9, f"{stage}_dyn_agg.{name}.grad: {err} vs scale {np.abs(want).max()}"
+    losses = []
+    for step in range(1, 6):
+        model.optimize_parameters(step)
+        losses.append(float(model.log_dict["l_g_pix"]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def _smooth_gt(B, H, seed):
+    """Synthetic ground truth with natural-image-like spectrum: a coarse random field upsampled bicubically plus a little
+    fine texture, in [0, 1] -- so that a x4 restoration has a finite, realistic PSNR (~25-35 dB)."""
+    import synth
+    coarse = torch.from_numpy(synth.uniform((B, 3, H // 16, H // 16), seed, 0.0, 1.0))
+    img = torch.nn.functional.interpolate(coarse, size=(H, H), mode="bicubic", align_corners=False)
+    img = img + 0.03 * torch.from_numpy(synth.gaussish((B, 3, H, H), seed + 1))
+    return img.clamp(0, 1)
+
+
+def test_cfg5_320_bf16_autocast_psnr_budget(dev):
+    """BASELINE configs[4]: CUFED5-shape inference at LR 320x320 / Ref 500x500 (zero-padded to 1280x1280) under bf16
+    autocast.  Criterion as the config states it: PSNR against the ground truth, computed as the reference's validation
+    does (tensor2img + metrics.psnr on [0,255] images, crop_border = scale = 4, also on Y -- ref_restoration_model.py:
+    338-347, options.py:56-57), must stay within 0.02 dB of the fp32 run.  The fp32 index map is also checked against the
+    oracle on row slices at this (largest) size."""
+    import c2m_oracle as oracle
+    from mmsr.utils import metrics
+    ext, mp, g = _build_chain(dev)
+    H = 1280
+    gt = _smooth_gt(1, H, 6000).to(dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    ref = torch.zeros((1, 3, H, H), device=dev)
+    ref[:, :, :500, :500] = _smooth_gt(1, 512, 6002)[:, :, :500, :500].to(dev)
+
+    def run():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        return g(lq, pre, ref_feat), feats
+
+    with torch.no_grad():
+        sr32, feats = run()
+        idx, _ = mp.match(feats)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            sr16, _ = run()
+    assert tuple(sr32.shape) == (1, 3, H, H) and torch.isfinite(sr16).all() and torch.isfinite(sr32).all()
+    f1 = oracle.feature_normalize(feats["dense_features1"][0].cpu().numpy())
+    f2 = oracle.feature_normalize(feats["dense_features2"][0].cpu().numpy())
+    hidx = idx[0].cpu().numpy()
+    assert hidx.shape == (318, 318)
+    for rows in ((0, 2), (200, 202), (316, 318)):
+        oi, _ = oracle.feature_match_index(f1, f2, 3, 1, 1, True, True, qrows=rows)
+        assert np.array_equal(hidx[rows[0]:rows[1]], oi[rows[0]:rows[1]])
+    m32 = metrics.validation_metrics(sr32, gt, crop_border=4)
+    m16 = metrics.validation_metrics(sr16.float(), gt, crop_border=4)
+    p32, p16 = float(m32["psnr"][0]), float(m16["psnr"][0])
+    y32, y16 = float(m32["psnr_y"][0]), float(m16["psnr_y"][0])
+    assert 15.0 < p32 < 60.0, p32   # a real restoration quality, not a degenerate image
+    assert abs(p16 - p32) <= 0.02, f"PSNR fp32 {p32:.4f} dB vs bf16 {p16:.4f} dB"
+    assert abs(y16 - y32) <= 0.02, f"PSNR_Y fp32 {y32:.4f} dB vs bf16 {y16:.4f} dB"
