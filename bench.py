@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- LR-Ref image pairs / second of the MI355X hot path on synthetic 160x160-LR / 500x500-Ref pairs.
+"""bench.py -- LR-Ref image pairs / second of the MI355X restoration path on synthetic 160x160-LR / 500x500-Ref pairs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload corr|restore]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload restore|corr]
 
-One "step" = one pass of the hot path over one batch of B=16 pairs per GPU (BASELINE.json configs[1]:
-"Batch-16 160x160 LR / 500x500 Ref, correlation+index-map only"): channel-normalise both 256x160x160 feature maps,
-3x3-patch correlation + arg-max index map, pre-offset maps at the three scales.  Inputs are resident in HBM before the
-timed region.  N>1: launched by torch.distributed.run, one rank per GPU, every rank its own batch (weak scaling, no
-data-path collective: pairs are independent -- SURVEY.md 8e); the barrier / max-over-ranks timing uses RCCL.
+Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: "Batch-16 full restoration forward
+(correlation + DCNv2 warp + decoder), 1xMI355X, fp32".  One "step" = one pass over one batch of B=16 pairs per GPU:
+ContrasExtractorSep on the bicubic-upsampled LR and the zero-padded Ref -> channel normalise -> 3x3 patch correlation /
+arg-max index map -> pre-offsets -> VGG19 taps of the Ref -> RestorationNet (content extractor, three DynAgg = DCNv2 warps,
+3 x 16 residual blocks, up-sampling tails) -> SR image [16,3,640,640].  Images and weights are resident in HBM before the
+timed region; weights are seeded random (no checkpoints offline), the offset heads are live (N(0, 0.01)).
+`--workload corr` times configs[1] alone (normalise + correlation + pre-offsets on synthetic features).
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, timed with HIP events on the
-launch stream through c2m_profile_*) and `cpu_baseline` (the reference's algorithm on PyTorch-CPU, bounded sample).
+N>1: launched by torch.distributed.run, one rank per GPU, every rank its own batch (weak scaling, no data-path
+collective: pairs are independent -- SURVEY.md 8e); the barrier / max-over-ranks timing uses RCCL.
+
+Prints ONE JSON line (rank 0): the contract fields, `stage_ms`, `roofline` (the hand-written kernel with the largest share
+of the step) + `roofline_kernels` (every hand-written hot kernel: HIP events on the launch stream through c2m_profile_*,
+FLOPs per SURVEY.md 8d), `configs1_corr_only` (the round-1 headline, kept as a sub-record) and `cpu_baseline` (the same
+forward for ONE pair on the host cores through oracle/cpu_chain.py, outside the timed region).
 """
 import argparse
 import json
@@ -27,8 +34,12 @@ import torch  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
+METRIC = "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)"
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
 def synth_features(B, C, h, valid, dev, seed):
     """N(0,1) features; the ref map carries the constant band a zero-padded 500x500 Ref leaves beyond 125/160
     (ref_cufed_dataset.py:107-114) -> exact ties exist, as in the reference's test-time data."""
@@ -42,29 +53,106 @@ def synth_features(B, C, h, valid, dev, seed):
     return fin, fref
 
 
-def corr_step(ops, fin, fref, h):
-    n1 = ops.feature_normalize(fin)
-    n2 = ops.feature_normalize(fref)
-    idx, val = ops.feature_match_index_batched(n1, n2, 3, 1, 1, True, True)
-    offs = ops.build_pre_offsets(idx, h, h)
-    return idx, val, offs
+def synth_images(B, h, dev, seed):
+    """img_in_lq ~ U(0,1) [B,3,h,h]; img_in_up = bicubic x4; img_ref ~ U(0,1) 500x500 zero-padded to 4h."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    lq = torch.rand((B, 3, h, h), generator=g, device=dev)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    ref = torch.zeros((B, 3, 4 * h, 4 * h), device=dev)
+    v = min(4 * h, (500 * 4 * h) // 640)
+    ref[:, :, :v, :v] = torch.rand((B, 3, v, v), generator=g, device=dev)
+    return lq, up, ref
 
 
+def build_models(dev, seed=1234):
+    from mmsr.models.archs.contras_extractor_arch import ContrasExtractorSep
+    from mmsr.models.archs.corres_generation_arch import CorrespondenceGenerationArch
+    from mmsr.models.archs.ref_restoration_arch import RestorationNet
+    import warnings
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # "VGG weights are RANDOM": intended here (synthetic benchmark)
+        ext = ContrasExtractorSep().eval()
+        mp = CorrespondenceGenerationArch(3, 1, ["relu1_1", "relu2_1", "relu3_1"], "vgg19").eval()
+    net = RestorationNet(64, 16, 8).eval()
+    for m in list(ext.modules()) + list(mp.modules()):
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+    for stage in ("small", "medium", "large"):   # live offsets (N(0, 0.01)) instead of the zero-initialised heads
+        torch.nn.init.normal_(getattr(net.dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask.weight, std=0.01)
+    return ext.to(dev), mp.to(dev), net.to(dev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# work models (SURVEY.md 8d)
+# ---------------------------------------------------------------------------------------------------------------------
 def corr_executed_flops(B, C, h):
-    """MFMA flops the sweep actually issues (tiles incl. halo / quantisation), per launch."""
+    """MFMA flops the correlation sweep actually issues (tiles incl. halo / quantisation), per launch."""
     tiles = ((h - 2 + 13) // 14) ** 2
     steps = ((h - 2 + 27) // 28) * h
     return B * tiles * (steps + 1) * 8 * (C // 2) * (2 * 32 * 32 * 2)
 
 
-def cpu_baseline(h, C, threads=None, budget_s=12.0):
-    """Reference algorithm (ref patches as conv2d filters, chunked running arg-max -- ref_map_util.py:26-86 as restated in
-    oracle/torch_port.py) on PyTorch-CPU.  Bounded sample: `rows` query pixel rows of ONE h x h pair against the full ref map
-    (cost is linear in query rows, pairs/s = (rows-2)/(h-2) / seconds).  A 48-row probe sizes the sample so that it runs
-    for roughly `budget_s` seconds (at most the whole pair)."""
+def corr_roofline(B, C, h, kms, n, traffic):
+    exec_flops = corr_executed_flops(B, C, h)
+    useful = B * 2.0 * (h * h) ** 2 * C                      # pixel-level products D[p][r]: the restructured minimum
+    algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9             # SURVEY.md 8d: 2*Nq*Nr*C*9 per pair
+    tf = lambda f: f / (kms * 1e-3) / 1e12 if kms > 0 else 0.0  # noqa: E731
+    return {"bound": "mfma", "kernel": f"corr_argmax_mfma_kernel<{C}>", "achieved": tf(exec_flops),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf(exec_flops) / FP32_MATRIX_PEAK_TFLOPS,
+            "traffic": traffic, "kernel_ms": kms, "launches_timed": n,
+            "frac_definition": "executed fp32 MFMA flops / peak (hardware utilisation, <= 1).  SURVEY 8d's algorithmic "
+                               "figure (the reference's conv2d formulation) is 8.6x the work this kernel needs: the 9-tap "
+                               "patch sum is taken over pixel-level dot products, so 8d-flops / time exceeds the peak",
+            "frac_executed_mfma": tf(exec_flops) / FP32_MATRIX_PEAK_TFLOPS,
+            "frac_useful_flops": tf(useful) / FP32_MATRIX_PEAK_TFLOPS,
+            "frac_sec8d_algorithmic": tf(algo) / FP32_MATRIX_PEAK_TFLOPS,
+            "executed_flops_per_launch": exec_flops, "useful_flops_per_launch": useful,
+            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": tf(algo)}
+
+
+def dcn_roofline(name, B, C, Co, H, kms, n):
+    flops = B * 2.0 * Co * 9 * C * H * H                     # SURVEY.md 8d: 2*Co*(9C)*H*W per sample
+    tf = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    return {"bound": "mfma", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": tf,
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "kernel_ms": kms, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+
+
+def conv_roofline(kms_total, flops_total, n):
+    tf = flops_total / (kms_total * 1e-3) / 1e12 if kms_total > 0 else 0.0
+    return {"bound": "mfma", "kernel": "conv3x3_nhwc_mfma (all decoder / extractor convolutions of one step)",
+            "achieved": tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MATRIX_PEAK_TFLOPS,
+            "traffic": None, "kernel_ms": kms_total, "launches_timed": n, "algorithmic_flops_per_launch": flops_total}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (outside the timed region, rank 0, N=1 only)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None):
+    """ONE pair of the same batch through the same forward on the host cores (oracle/cpu_chain.py): stock torch-CPU
+    convolutions, the reference's conv2d-filter correlation algorithm (ref_map_util.py:26-86), oracle pre-offsets and
+    oracle DCNv2 (the reference has no CPU DCNv2).  ~10-20 s on the GPU box's cores."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import cpu_chain
+    import c2m_oracle
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    c2m_oracle.set_num_threads(min(threads, 64))
+    tm = {}
+    t0 = time.perf_counter()
+    sr, idx, _ = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"1 of the {lq.shape[0]} pairs of one step, whole forward (extractor, correlation as conv2d filters + "
+                      f"running max, pre-offsets, VGG taps, RestorationNet with oracle DCNv2) on PyTorch-CPU + C oracle, "
+                      f"{dt:.1f}s", "stage_s": tm}, sr, idx
+
+
+def cpu_baseline_corr(h, C, threads=None, budget_s=12.0):
+    """configs[1] alone: reference algorithm on PyTorch-CPU, a bounded slice of query rows of one pair."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch_port
-    import c2m_oracle
     threads = threads or os.cpu_count()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1234)
@@ -84,24 +172,12 @@ def cpu_baseline(h, C, threads=None, budget_s=12.0):
         rows = want
         dt = run(rows)
     frac = (rows - 2) / (h - 2)
-    # one host thread, 8 query rows (SURVEY.md 8d asks for a 1-thread figure beside the all-core one)
-    torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    torch_port.feature_match_index_conv(fi_full[:, :8].contiguous(), fr, 3, 1, 1, True, True)
-    dt_1 = time.perf_counter() - t0
-    torch.set_num_threads(threads)
-    # the C oracle (pixel-level restructuring, OpenMP) on a 48-row sample, for context
-    c2m_oracle.set_num_threads(min(threads, 32))
-    t0 = time.perf_counter()
-    c2m_oracle.feature_match_index(fi_full[:, :48].contiguous().numpy(), fr.numpy(), 3, 1, 1, True, True)
-    dt_c = time.perf_counter() - t0
     return {"value": frac / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{rows} of {h} query rows of one {h}x{h}x{C} pair vs full ref map, PyTorch-CPU conv2d+max "
-                      f"(reference algorithm, oracle/torch_port.py), {dt:.2f}s; linear extrapolation to a pair",
-            "one_thread_pairs_per_s": (6 / (h - 2)) / dt_1,
-            "oracle_c_openmp_pairs_per_s": (46 / (h - 2)) / dt_c, "oracle_c_threads": min(threads, 32)}
+                      f"(reference algorithm, oracle/torch_port.py), {dt:.2f}s; linear extrapolation to a pair"}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +185,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="pairs per GPU per step")
     ap.add_argument("--lr", type=int, default=160, help="LR size = feature-map size")
+    ap.add_argument("--workload", choices=("restore", "corr"), default="restore")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,8 +205,6 @@ def main():
     import c2m_amd
     ops = c2m_amd.ops
     B, C, h = args.batch, 256, args.lr
-    valid = (500 * h) // 640  # 500x500 Ref inside the 640x640 padded canvas, at feature scale
-    fin, fref = synth_features(B, C, h, valid, dev, 1234 + rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -137,52 +212,138 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = corr_step(ops, fin, fref, h)
-    c2m_amd.profile_enable(True)
-    c2m_amd.profile_collect()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = corr_step(ops, fin, fref, h)
-    sync()
-    dt = time.perf_counter() - t0
-    kern = [ms for (name, ms) in c2m_amd.profile_collect() if name == "corr_argmax_mfma"]
-    c2m_amd.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert int(out[0].min()) >= 0 and int(out[0].max()) < (h - 2) ** 2
+    def timed(step_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        c2m_amd.profile_enable(True)
+        c2m_amd.profile_collect()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step_fn()
+        sync()
+        dt = time.perf_counter() - t0
+        prof = c2m_amd.profile_collect(capacity=65536)
+        c2m_amd.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof, out
+
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "corr_pmc_traffic.json")
+    if os.path.exists(tfile) and (B, h) == (16, 160):
+        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+
+    # ---- configs[1] leg: correlation only on synthetic features (always run: sub-record of the default line) -------
+    valid = (500 * h) // 640  # 500x500 Ref inside the 640x640 padded canvas, at feature scale
+    fin, fref = synth_features(B, C, h, valid, dev, 1234 + rank)
+
+    def corr_step():
+        n1 = ops.feature_normalize(fin)
+        n2 = ops.feature_normalize(fref)
+        idx, val = ops.feature_match_index_batched(n1, n2, 3, 1, 1, True, True)
+        return idx, val, ops.build_pre_offsets(idx, h, h)
+
+    if args.workload == "corr":
+        dt, prof, out = timed(corr_step)
+        assert int(out[0].min()) >= 0 and int(out[0].max()) < (h - 2) ** 2
+        if rank == 0:
+            kern = [ms for (name, ms) in prof if name == "corr_argmax_mfma"]
+            kms = sum(kern) / max(len(kern), 1)
+            line = {"metric": METRIC + " -- correlation + index map only", "value": B * world * args.steps / dt,
+                    "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), feature "
+                                           "normalise + 3x3 correlation/arg-max index map + pre-offset maps (NO DCNv2 / decoder)",
+                               "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
+                    "roofline": corr_roofline(B, C, h, kms, len(kern), traffic)}
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline_corr(h, C)
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- configs[2]: full restoration forward ---------------------------------------------------------------------
+    ext, mp, net = build_models(dev)
+    lq, up, ref = synth_images(B, h, dev, 1234 + rank)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
+    it = [0]
+
+    @torch.no_grad()
+    def restore_step():
+        e = ev[it[0]]
+        it[0] += 1
+        e[0].record()
+        feats = ext(up, ref)
+        e[1].record()
+        pre, ref_feat = mp(feats, ref)
+        e[2].record()
+        sr = net(lq, pre, ref_feat)
+        e[3].record()
+        return sr
+
+    dt, prof, sr = timed(restore_step)
+    assert tuple(sr.shape) == (B, 3, 4 * h, 4 * h) and bool(torch.isfinite(sr).all())
+    stage = {"extractor": 0.0, "correspondence": 0.0, "restoration": 0.0}
+    for e in ev[args.warmup:]:
+        for k, name in enumerate(stage):
+            stage[name] += e[k].elapsed_time(e[k + 1]) / args.steps
+
+    # configs[1] sub-record (short: 3 steps)
+    sub = None
+    if rank == 0:
+        steps_keep, args.steps = args.steps, 3
+        sdt, sprof, _ = timed(corr_step) if dist is None else (None, None, None)
+        args.steps = steps_keep
+        if sdt is not None:
+            sk = [ms for (name, ms) in sprof if name == "corr_argmax_mfma"]
+            sub = {"workload": "configs[1]: normalise + correlation/arg-max + pre-offsets on synthetic features (round-1 headline)",
+                   "pairs_per_s": B * 3 / sdt, "ms_per_step": sdt / 3 * 1e3, "corr_kernel_ms": sum(sk) / max(len(sk), 1)}
 
     if rank == 0:
-        pairs = B * world * args.steps
-        kms = sum(kern) / max(len(kern), 1)
-        exec_flops = corr_executed_flops(B, C, h)
-        algo_flops = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9      # 2*Nq*Nr*C*9 per pair
-        achieved = exec_flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "corr_pmc_traffic.json")
-        if os.path.exists(tfile) and (B, h) == (16, 160):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        kern = {}
+        for name, ms in prof:
+            kern.setdefault(name, []).append(ms)
+        rl = []
+        ck = kern.get("corr_argmax_mfma", [])
+        if ck:
+            rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), traffic))
+        dk = kern.get("dcn_v2_forward", [])
+        layers = (("small", 256, h), ("medium", 128, 2 * h), ("large", 64, 4 * h))
+        if dk and len(dk) % 3 == 0:   # launch order inside a step: small, medium, large (ref_restoration_arch.py:152-180)
+            for k, (lname, ch, hh) in enumerate(layers):
+                mine = dk[k::3]
+                rl.append(dcn_roofline(lname, B, ch, ch, hh, sum(mine) / len(mine), len(mine)))
+            tot = sum(dk) / (len(dk) // 3)
+            flops = sum(B * 2.0 * ch * 9 * ch * hh * hh for _, ch, hh in layers)
+            rl.append({"bound": "mfma", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
+                       "achieved": flops / (tot * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / (tot * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel_ms": tot,
+                       "launches_timed": len(dk), "algorithmic_flops_per_launch": flops,
+                       "north_star_target": ">= 0.50 MFMA utilisation on DCNv2 forward at batch 16"})
+        cv = kern.get("conv3x3_mfma", [])
+        if cv and hasattr(ops, "conv_flops_of_last_steps"):
+            per_step_ms = sum(cv) / args.steps
+            rl.append(conv_roofline(per_step_ms, ops.conv_flops_of_last_steps() / args.steps, len(cv)))
+        dominant = max(rl, key=lambda r: r["kernel_ms"]) if rl else None
         line = {
-            "metric": "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)",
-            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), "
-                                   "feature normalise + 3x3 correlation/arg-max index map + pre-offset maps, "
-                                   f"{B} pairs per GPU per step", "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
-            "roofline": {"bound": "mfma", "kernel": "corr_argmax_mfma_kernel<256>", "achieved": achieved,
-                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-                         "traffic": traffic, "kernel_ms": kms, "launches_timed": len(kern),
-                         "flops_counted": "executed fp32 MFMA flops per launch (pixel-level restructuring incl. halo)",
-                         "executed_flops_per_launch": exec_flops,
-                         "algorithmic_flops_per_launch": algo_flops,
-                         "algorithmic_equiv_tflops": algo_flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0},
+            "metric": METRIC, "value": B * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[2]: batch-{B} full restoration forward (extractor + correlation/index map + "
+                                   f"pre-offsets + VGG taps + RestorationNet with 3 DCNv2 warps + decoder), LR {h}x{h}, Ref "
+                                   f"500x500 zero-padded to {4*h}x{4*h}, SR {4*h}x{4*h}, fp32, {B} pairs per GPU per step",
+                       "parallelism": f"dp{world} (batch-sharded, no collective)"},
+            "stage_ms": stage, "roofline": dominant, "roofline_kernels": rl, "configs1_corr_only": sub,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(h, C)
+            base, sr_cpu, _ = cpu_baseline_restore(ext, mp, net, lq, up, ref)
+            base["sr_max_abs_diff_gpu_vs_cpu_pair0"] = float((sr[0].cpu() - sr_cpu[0]).abs().max())
+            line["cpu_baseline"] = base
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -167,23 +167,71 @@ def full160_inputs(b):
 
 
 FULL160_PAIRS = 16
+NEAR_TIE_MARGIN = 2e-6   # fp32 rounding uncertainty of a 2304-term dot product of this magnitude (sqrt(n) * 2^-24 * sum|a.b|)
+
+
+def score_fp64(fi, fr, y, x, n):
+    """Normalised correlation of query patch (y, x) with ref patch n in float64 (ref_map_util.py:62-69 in exact-ish arithmetic)."""
+    wrp = fr.shape[2] - 2
+    q = torch.from_numpy(np.ascontiguousarray(fi[:, y:y + 3, x:x + 3])).double().reshape(-1)
+    ry, rx = divmod(int(n), wrp)
+    r = torch.from_numpy(np.ascontiguousarray(fr[:, ry:ry + 3, rx:rx + 3])).double().reshape(-1)
+    return float((r / (r.norm() + 1e-5) * q).sum())
+
+
+def near_ties(b, fi, fr, ref_idx):
+    """Queries where the reference's fp32 arg-max is NOT determined beyond fp32 rounding: the canonical-order oracle picks
+    another candidate and the two scores differ by less than NEAR_TIE_MARGIN in float64.  Rows: (pair, y, x, reference
+    index, other index, fp64 score(other) - fp64 score(reference) in units of 1e-12).  A disagreement with a LARGER margin
+    would be a real defect and aborts the generation."""
+    oi, _ = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
+    rows = []
+    for (y, x) in np.argwhere(oi != ref_idx):
+        gap = score_fp64(fi, fr, y, x, oi[y, x]) - score_fp64(fi, fr, y, x, ref_idx[y, x])
+        assert abs(gap) < NEAR_TIE_MARGIN, (b, y, x, gap)
+        rows.append((b, int(y), int(x), int(ref_idx[y, x]), int(oi[y, x]), int(round(gap * 1e12))))
+        print("near tie: pair", b, "query", (int(y), int(x)), "reference", int(ref_idx[y, x]), "oracle", int(oi[y, x]),
+              "fp64 gap", gap, flush=True)
+    return rows
 
 
 def make_full160():
-    """Reference index maps (uint16: Nr = 24964 < 65536) of 16 distinct full-size pairs + values of pair 0."""
+    """Reference index maps (uint16: Nr = 24964 < 65536) of 16 distinct full-size pairs + values of pair 0 + the list of
+    fp32-indeterminate near-ties (see near_ties)."""
     rmu = load_ref_map_util()
     torch.set_num_threads(os.cpu_count())
-    out = {}
+    out, ties = {}, []
+    path = os.path.join(HERE, "corr_full160_golden.npz")
+    have = dict(np.load(path)) if (os.path.exists(path) and "--reuse-reference" in sys.argv) else {}
     for b in range(FULL160_PAIRS):
         fi, fr = full160_inputs(b)
-        idx, val = rmu.feature_match_index(torch.from_numpy(fi), torch.from_numpy(fr), patch_size=3, input_stride=1,
-                                           ref_stride=1, is_norm=True, norm_input=True)
-        assert int(idx.max()) < 65536
-        out[f"idx{b}"] = idx.numpy().astype(np.uint16)
-        if b == 0:
-            out["val0"] = val.numpy().astype(np.float32)
-        print("full160 pair", b, "idx range", int(idx.min()), int(idx.max()), flush=True)
-    np.savez_compressed(os.path.join(HERE, "corr_full160_golden.npz"), **out)
+        if f"idx{b}" in have:   # reference output from an earlier run of this script (30 s per pair); only re-classify
+            out[f"idx{b}"] = have[f"idx{b}"]
+            if b == 0:
+                out["val0"] = have["val0"]
+        else:
+            idx, val = rmu.feature_match_index(torch.from_numpy(fi), torch.from_numpy(fr), patch_size=3, input_stride=1,
+                                               ref_stride=1, is_norm=True, norm_input=True)
+            assert int(idx.max()) < 65536
+            out[f"idx{b}"] = idx.numpy().astype(np.uint16)
+            if b == 0:
+                out["val0"] = val.numpy().astype(np.float32)
+        ties += near_ties(b, fi, fr, out[f"idx{b}"].astype(np.int64))
+        print("full160 pair", b, "idx range", int(out[f"idx{b}"].min()), int(out[f"idx{b}"].max()), flush=True)
+    out["near_ties"] = np.array(ties, np.int64).reshape(-1, 6)
+    np.savez_compressed(path, **out)
+
+
+def check_against_reference_golden(got, ref_idx, ties, b, what):
+    """Shared by the tests: `got` (index map of pair b) equals the reference's map everywhere except at the listed
+    fp32-indeterminate near-ties, where it must be one of the two fp64-equivalent candidates."""
+    ref_idx = ref_idx.astype(np.int64)
+    bad = np.argwhere(got != ref_idx)
+    allowed = {(int(t[1]), int(t[2])): int(t[4]) for t in ties if int(t[0]) == b}
+    for (y, x) in bad:
+        assert (int(y), int(x)) in allowed and int(got[y, x]) == allowed[(int(y), int(x))], \
+            f"{what}: pair {b} query ({y},{x}): got {got[y, x]}, reference {ref_idx[y, x]} (not a listed near-tie)"
+    return len(bad)
 
 
 CFG5_ROWS = ((0, 6), (157, 163), (314, 320))   # query pixel-row slices (each gives 4 query patch rows)

@@ -140,18 +140,20 @@ def test_full_size_160_properties(env, dev):
 def test_full_size_160_batch16_whole_maps_vs_reference_and_oracle(env, dev, golden_dir):
     """BASELINE configs[1]: ONE launch over a batch of 16 distinct 160x160x256 pairs.  Every whole index map equals the
     map the reference's own Python produced for that pair (tests/golden/corr_full160_golden.npz: its two-chunk path with
-    the strict-> merge, constant-band ties); pairs 0 and 15 additionally equal the oracle on ALL rows, indices and values
-    bitwise."""
+    the strict-> merge, constant-band ties) -- except at the fixture's listed fp32-indeterminate near-ties (3 of 399 424
+    queries, float64 margins < 2e-7: the reference's oneDNN summation order decides those; there the HIP result must be
+    the other listed candidate, which is the float64-true maximum).  Pairs 0 and 15 additionally equal the oracle on ALL
+    rows, indices and values bitwise."""
     ops, oracle, _ = env
-    from make_golden import FULL160_PAIRS, full160_inputs
+    from make_golden import FULL160_PAIRS, check_against_reference_golden, full160_inputs
     g = np.load(f"{golden_dir}/corr_full160_golden.npz")
     pairs = [full160_inputs(b) for b in range(FULL160_PAIRS)]
     fi = torch.stack([torch.from_numpy(p[0]) for p in pairs]).to(dev)
     fr = torch.stack([torch.from_numpy(p[1]) for p in pairs]).to(dev)
     idx, val = ops.feature_match_index_batched(fi, fr, 3, 1, 1, True, True)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
-    for b in range(FULL160_PAIRS):
-        assert np.array_equal(idx[b], g[f"idx{b}"].astype(np.int64)), f"pair {b}: HIP index map != reference golden"
+    ntie = sum(check_against_reference_golden(idx[b], g[f"idx{b}"], g["near_ties"], b, "HIP") for b in range(FULL160_PAIRS))
+    assert ntie == len(g["near_ties"])   # canonical order: the HIP kernel resolves every listed near-tie like the oracle
     np.testing.assert_allclose(val[0], g["val0"], rtol=0, atol=2e-6)
     for b in (0, FULL160_PAIRS - 1):
         oi, ov = oracle.feature_match_index(pairs[b][0], pairs[b][1], 3, 1, 1, True, True)

@@ -64,12 +64,31 @@ def test_pre_offsets_match_reference(golden_dir):
 def test_full_size_160_pair_matches_reference(golden_dir):
     """BASELINE configs[1]/[2] size: the whole 158x158 index map of pair 0 against the reference's output (its two-chunk
     path with the strict-> merge, ref_map_util.py:54-76; constant band -> thousands of exact ties)."""
-    from make_golden import full160_inputs
+    from make_golden import check_against_reference_golden, full160_inputs
     g = np.load(f"{golden_dir}/corr_full160_golden.npz")
     fi, fr = full160_inputs(0)
     idx, val = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
-    assert np.array_equal(idx, g["idx0"].astype(np.int64))
+    assert check_against_reference_golden(idx, g["idx0"], g["near_ties"], 0, "oracle") == 0   # pair 0 has no near-tie
     np.testing.assert_allclose(val, g["val0"], rtol=0, atol=2e-6)
+
+
+def test_full_size_near_tie_list_is_small_and_within_fp32_noise(golden_dir):
+    """The reference's arg-max is an fp32 computation in oneDNN's summation order; on 399 424 full-size queries it
+    disagrees with the canonical-order oracle at a handful of near-ties whose float64 margin is far below fp32 rounding
+    noise (and there the oracle's pick is the float64-true maximum).  Re-derive one of them here."""
+    from make_golden import FULL160_PAIRS, NEAR_TIE_MARGIN, full160_inputs, score_fp64
+    g = np.load(f"{golden_dir}/corr_full160_golden.npz")
+    ties = g["near_ties"]
+    assert len(ties) <= 8 and len(ties) < 1e-4 * FULL160_PAIRS * 158 * 158
+    assert (np.abs(ties[:, 5]) * 1e-12 < NEAR_TIE_MARGIN).all()
+    assert (ties[:, 5] >= 0).all()   # the oracle's candidate is the better one in float64 every time
+    b, y, x, ref_i, alt_i, gap = (int(v) for v in ties[0])
+    fi, fr = full160_inputs(b)
+    assert int(g[f"idx{b}"][y, x]) == ref_i
+    got = score_fp64(fi, fr, y, x, alt_i) - score_fp64(fi, fr, y, x, ref_i)
+    assert abs(got - gap * 1e-12) < 1e-9
+    oi, _ = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=(y, y + 1))
+    assert int(oi[y, x]) == alt_i
 
 
 def test_cfg5_row_slices_match_reference(golden_dir):
