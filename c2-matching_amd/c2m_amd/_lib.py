@@ -17,6 +17,20 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _lib = None
 
 
+class ConvSrc(ctypes.Structure):
+    """c2m_conv_src of include/c2m_hip.h"""
+    _fields_ = [("ptr", _vp), ("C", _i), ("pix_pitch", _i), ("row_pitch", _i), ("img_pitch", ctypes.c_longlong)]
+
+
+class Conv3x3Desc(ctypes.Structure):
+    """c2m_conv3x3_desc of include/c2m_hip.h"""
+    _fields_ = [("B", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("nsrc", _i), ("src", ConvSrc * 2),
+                ("wr", _vp), ("bias", _vp), ("act", _i), ("slope", ctypes.c_float), ("out_mode", _i), ("out", _vp),
+                ("out_pix_pitch", _i), ("out_row_pitch", _i), ("out_img_pitch", ctypes.c_longlong), ("res1", _vp),
+                ("res2", _vp), ("mask_out", _vp), ("flow", _vp), ("fh", _i), ("fw", _i), ("scale", _i), ("n_off", _i),
+                ("abs_sum", _vp)]
+
+
 class C2MError(RuntimeError):
     pass
 
@@ -43,6 +57,16 @@ def _declare(L):
     L.c2m_dcn_v2_forward_bf16mma_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _vp, _sz]
     L.c2m_dcn_v2_backward_f32.argtypes = [_vp] * 7 + [_i] * 14 + [_vp] * 5 + [_vp, _sz]
     L.c2m_dcn_fuse_offsets_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+    L.c2m_nchw_to_nhwc_bordered_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+    L.c2m_dcn_v2_relayout_bytes.restype = _sz
+    L.c2m_dcn_v2_relayout_bytes.argtypes = [_i] * 5
+    L.c2m_dcn_v2_relayout_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp]
+    L.c2m_dcn_v2_forward_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_float]
+    L.c2m_conv3x3_relayout_bytes.restype = _sz
+    L.c2m_conv3x3_relayout_bytes.argtypes = [_i, _i]
+    L.c2m_conv3x3_relayout_f32.argtypes = [_vp, _vp, _i, _i, _vp]
+    L.c2m_conv3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(Conv3x3Desc)]
+    L.c2m_index_to_flow_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
 
 
 def lib():
@@ -75,7 +99,7 @@ def device_arch():
 
 
 KERNEL_NAMES = {1: "corr_argmax_mfma", 2: "corr_argmax_generic", 3: "dcn_v2_forward", 4: "dcn_v2_backward_data",
-                5: "dcn_v2_backward_weight"}
+                5: "dcn_v2_backward_weight", 6: "conv3x3_mfma"}
 
 
 def profile_enable(on=True):

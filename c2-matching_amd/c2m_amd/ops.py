@@ -158,3 +158,240 @@ def dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, kernel_taps, abs_s
                                                        abs_sum.data_ptr() if abs_sum is not None else None),
                    "c2m_dcn_fuse_offsets_f32")
     return offset, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3x3 convolution, channels-last, fused epilogue (csrc/conv3x3.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+_conv_flops = [0.0]
+
+
+def conv_flops_of_last_steps(reset=True):
+    """2*Cout*9*Cin*H*W*B summed over the conv3x3 calls since the last reset (bench.py's roofline line)."""
+    v = _conv_flops[0]
+    if reset:
+        _conv_flops[0] = 0.0
+    return v
+
+
+class _WeightCache:
+    """Re-laid-out conv weights, keyed by the parameter tensor and its version counter: inference re-uses them across
+    calls; an optimiser step (in-place update -> new _version) or load_state_dict invalidates them."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, weight, pad_cin_to=None):
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
+        hit = self._d.get(id(weight))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+            raise _lib.C2MError("conv3x3: weight must be a float32 GPU tensor [Cout, Cin, 3, 3]")
+        Co, Ci = w.shape[:2]
+        if pad_cin_to is not None and Ci < pad_cin_to:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad_cin_to - Ci))
+            Ci = pad_cin_to
+        w = w.contiguous()
+        L = _lib.lib()
+        nbytes = L.c2m_conv3x3_relayout_bytes(Ci, Co)
+        if nbytes == 0:
+            raise _lib.C2MError(f"conv3x3: input channels must be a multiple of 32, got {Ci}")
+        wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(L.c2m_conv3x3_relayout_f32(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout_f32")
+        self._d[id(weight)] = (key, wr)
+        return wr
+
+
+_wcache = _WeightCache()
+
+
+def _nhwc_src(t, name):
+    """channels_last float32 GPU tensor (logical [B,C,H,W], channel stride 1) or a channel slice of one -> ConvSrc."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise _lib.C2MError(f"{name} must be a 4-D float32 GPU tensor")
+    sb, sc, sh, sw = t.stride()
+    if sc != 1:
+        raise _lib.C2MError(f"{name} must be channels-last (stride 1 along C); got strides {t.stride()}")
+    return _lib.ConvSrc(t.data_ptr(), t.shape[1], sw, sh, sb)
+
+
+def empty_nhwc(B, C, H, W, device):
+    return torch.empty((B, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None):
+    """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
+
+    srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
+    the (zero-padded) weight is not accepted -- pad the tensor).  out_mode: "nhwc" -> channels_last [B,Cout,H,W];
+    "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous."""
+    srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
+    B, _, H, W = srcs[0].shape
+    Cin = sum(s.shape[1] for s in srcs)
+    Cout = weight.shape[0]
+    dev = srcs[0].device
+    wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None)
+    d = _lib.Conv3x3Desc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
+    for k, s in enumerate(srcs):
+        if tuple(s.shape[2:]) != (H, W) or s.shape[0] != B:
+            raise _lib.C2MError("conv3x3: sources must share B, H, W")
+        d.src[k] = _nhwc_src(s, f"src{k}")
+    d.wr = wr.data_ptr()
+    if bias is not None:
+        bias = _dev_f32(bias.detach(), "bias")
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act, d.slope = int(act), float(slope)
+    if out_mode == "nhwc":
+        if out is None:
+            out = empty_nhwc(B, Cout, H, W, dev)
+        d.out_mode = 0
+        o = _nhwc_src(out, "out")
+        d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
+        for name, r in (("res1", res1), ("res2", res2)):
+            if r is not None:
+                rs = _nhwc_src(r, name)
+                if (rs.pix_pitch, rs.row_pitch, rs.img_pitch) != (o.pix_pitch, o.row_pitch, o.img_pitch) or r.shape != out.shape:
+                    raise _lib.C2MError(f"{name} must have the geometry of the output")
+                setattr(d, name, r.data_ptr())
+    elif out_mode == "pixel_shuffle":
+        out = empty_nhwc(B, Cout // 4, 2 * H, 2 * W, dev)
+        d.out_mode = 1
+        o = _nhwc_src(out, "out")
+        d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
+    elif out_mode == "nchw":
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        d.out_mode = 2
+    else:
+        raise _lib.C2MError(f"unknown out_mode {out_mode}")
+    d.out = out.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
+    _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
+    return out
+
+
+def index_to_flow(max_idx):
+    """max_idx int64 [B,hq,wq] -> flow float32 [B,hq,wq,2] (x, y), un-padded (corres_generation_arch.py:29-46)."""
+    if not max_idx.is_cuda or max_idx.dtype != torch.int64 or max_idx.dim() != 3:
+        raise _lib.C2MError("max_idx must be an int64 GPU tensor [B, hq, wq]")
+    mi = max_idx.contiguous()
+    B, hq, wq = mi.shape
+    flow = torch.empty((B, hq, wq, 2), dtype=torch.float32, device=mi.device)
+    with torch.cuda.device(mi.device):
+        _lib.check(_lib.lib().c2m_index_to_flow_f32(_stream(), mi.data_ptr(), B, hq, wq, flow.data_ptr()), "c2m_index_to_flow_f32")
+    return flow
+
+
+def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, abs_sum=None):
+    """The DCN offset/mask head (conv_offset_mask of DCN_sep_pre_multi_offset, dcn_v2.py:229-245) fused with the
+    pre-offset construction: -> (offset [B,2*dg*9,H,W], mask [B,dg*9,H,W]) planar, ready for dcn_v2_forward.
+    flow: index_to_flow(max_idx) of the matched LR features (or None: no pre-offset); scale = H / h (1, 2, 4)."""
+    srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
+    B, _, H, W = srcs[0].shape
+    Cin = sum(s.shape[1] for s in srcs)
+    dg = int(deformable_groups)
+    Cout = weight.shape[0]
+    if Cout != 3 * dg * 9:
+        raise _lib.C2MError("conv3x3_dcn_head: weight must have 3*dg*9 output channels")
+    dev = srcs[0].device
+    wr = _wcache.get(weight)
+    d = _lib.Conv3x3Desc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
+    for k, s in enumerate(srcs):
+        d.src[k] = _nhwc_src(s, f"src{k}")
+    d.wr = wr.data_ptr()
+    bias = _dev_f32(bias.detach(), "bias")
+    d.bias = bias.data_ptr()
+    d.out_mode = 3
+    offset = torch.empty((B, 2 * dg * 9, H, W), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, dg * 9, H, W), dtype=torch.float32, device=dev)
+    d.out, d.mask_out, d.n_off, d.scale = offset.data_ptr(), mask.data_ptr(), 2 * dg * 9, int(scale)
+    if flow is not None:
+        if flow.dtype != torch.float32 or not flow.is_cuda or flow.dim() != 4 or flow.shape[0] != B or flow.shape[3] != 2:
+            raise _lib.C2MError("flow must be float32 [B, fh, fw, 2] on the GPU")
+        flow = flow.contiguous()
+        d.flow, d.fh, d.fw = flow.data_ptr(), flow.shape[1], flow.shape[2]
+    if abs_sum is not None:
+        if abs_sum.dtype != torch.float64 or abs_sum.numel() < 256 or not abs_sum.is_cuda:
+            raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
+        d.abs_sum = abs_sum.data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
+    _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
+    return offset, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DCNv2 forward on the fused decoder path: bordered channels-last input shared with the convolutions, cached weights,
+# channels-last output with the activation folded in
+# ---------------------------------------------------------------------------------------------------------------------
+class BorderedNHWC:
+    """Zero-bordered channels-last copy [B][H+3][W+3][C] of an NCHW feature map (what the DCNv2 kernels gather from)."""
+
+    def __init__(self, x):
+        x = _dev_f32(x, "x")
+        self.B, self.C, self.H, self.W = x.shape
+        self.buf = torch.empty((self.B, self.H + 3, self.W + 3, self.C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().c2m_nchw_to_nhwc_bordered_f32(_stream(), x.data_ptr(), self.B, self.C, self.H, self.W,
+                                                               self.buf.data_ptr()), "c2m_nchw_to_nhwc_bordered_f32")
+
+    def interior(self):
+        """Logical [B,C,H,W] channels-last view of the image inside the border (a conv3x3 source)."""
+        return self.buf[:, 1:self.H + 1, 1:self.W + 1, :].permute(0, 3, 1, 2)
+
+
+class _DcnWeightCache(_WeightCache):
+    def get(self, weight, dg):
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), dg, weight.device.index)
+        hit = self._d.get(id(weight))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = _dev_f32(weight.detach(), "weight")
+        Co, C, kh, kw = w.shape
+        L = _lib.lib()
+        nbytes = L.c2m_dcn_v2_relayout_bytes(C, Co, kh, kw, dg)
+        if nbytes == 0:
+            raise _lib.C2MError("dcn_v2_forward_nhwc: geometry is not on the channels-last path")
+        wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(L.c2m_dcn_v2_relayout_f32(_stream(), w.data_ptr(), C, Co, kh, kw, dg, wt.data_ptr()), "c2m_dcn_v2_relayout_f32")
+        self._d[id(weight)] = (key, wt)
+        return wt
+
+
+_dcn_wcache = _DcnWeightCache()
+
+
+def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_groups, act=ACT_NONE, slope=0.1,
+                        nhwc_out=True):
+    """3x3 / stride 1 / pad 1 DCNv2 forward from a BorderedNHWC input; planar offset / mask as dcn_v2_forward takes them.
+    -> channels_last [B,Co,H,W] (nhwc_out) or contiguous NCHW, with the activation applied."""
+    if not isinstance(inp_bordered, BorderedNHWC):
+        raise _lib.C2MError("inp_bordered must be a BorderedNHWC")
+    B, C, H, W = inp_bordered.B, inp_bordered.C, inp_bordered.H, inp_bordered.W
+    Co = weight.shape[0]
+    dg = int(deformable_groups)
+    offset, mask, bias = _dev_f32(offset, "offset"), _dev_f32(mask, "mask"), _dev_f32(bias.detach(), "bias")
+    if tuple(offset.shape) != (B, 2 * dg * 9, H, W) or tuple(mask.shape) != (B, dg * 9, H, W):
+        raise _lib.C2MError("offset/mask shape does not match [B, 2*dg*9, H, W] / [B, dg*9, H, W]")
+    wt = _dcn_wcache.get(weight, dg)
+    dev = offset.device
+    if nhwc_out:
+        out = empty_nhwc(B, Co, H, W, dev)
+        o = _nhwc_src(out, "out")
+        pitches = (1, o.pix_pitch, o.row_pitch, o.img_pitch)
+    else:
+        out = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+        pitches = (0, 0, 0, 0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f32(_stream(), inp_bordered.buf.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                         offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1, 1,
+                                                         1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope)),
+                   "c2m_dcn_v2_forward_nhwc_f32")
+    return out

@@ -12,7 +12,7 @@ void set_last_error(hipError_t e) { g_last_error = e; }
 
 namespace c2m {
 namespace {
-constexpr int kMaxProf = 512;
+constexpr int kMaxProf = 16384;   // a full restoration forward launches ~150 timed kernels per step
 struct ProfState {
   std::mutex mu;
   bool on = false;

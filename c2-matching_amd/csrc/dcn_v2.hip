@@ -36,6 +36,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Geom {
   int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg;
   int Ho, Wo, T, CPG, Ktot, KtotPad, CoPad;
+  // output of the channels-last forward kernel: planar NCHW (the reference's layout) or channels-last with pitches (in
+  // floats) + optional LeakyReLU, for the fused decoder path (the lrelu after every DynAgg, ref_restoration_arch.py:152-154)
+  int out_nhwc, out_pix_pitch, out_row_pitch, act;
+  long long out_img_pitch;
+  float slope;
 };
 
 // bilinear sampling state of one (pixel, group, tap)
@@ -580,6 +585,31 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
     }
   }
 
+  if (g.out_nhwc) {
+    // channels-last store (+ activation): the lane's rows (r & 3) are 4 consecutive output channels = one float4
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int py = pc[nt] / g.Wo, px = pc[nt] - py * g.Wo;
+      float* op = out + (size_t)b * g.out_img_pitch + (size_t)py * g.out_row_pitch + (size_t)px * g.out_pix_pitch;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int o = ob * MW + mt * 32 + 8 * qd + 4 * hi;
+          if (o < g.Co && pok[nt]) {   // Co % 4 == 0 on this path (checked by the launcher)
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[mt][nt][4 * qd + e] + bias[o + e];
+              if (g.act == 2) v[e] = v[e] > 0.0f ? v[e] : v[e] * g.slope;
+              else if (g.act == 1) v[e] = fmaxf(v[e], 0.0f);
+            }
+            *reinterpret_cast<f32x4*>(op + o) = v;
+          }
+        }
+    }
+    return;
+  }
   float* out_b = out + (size_t)b * g.Co * HWo;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -1133,6 +1163,7 @@ int make_geom(Geom& g, int B, int C, int H, int W, int Co, int kh, int kw, int s
     return C2M_ERR_INVALID_ARG;
   g.B = B; g.C = C; g.H = H; g.W = W; g.Co = Co; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
   g.dh = dh; g.dw = dw; g.dg = dg;
+  g.out_nhwc = 0; g.out_pix_pitch = 0; g.out_row_pitch = 0; g.out_img_pitch = 0; g.act = 0; g.slope = 0.0f;
   g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   if (g.Ho <= 0 || g.Wo <= 0) return C2M_ERR_INVALID_ARG;
@@ -1239,22 +1270,39 @@ void launch_nhwc_copy(hipStream_t st, const float* input, int B, int C, int H, i
                        st, input, C, H, W, out);
 }
 
+// Options of the fused decoder path (c2m_dcn_v2_forward_nhwc_f32): the caller already holds the zero-bordered channels-last
+// copy (shared with the offset convolutions) and the re-laid-out weights (cached while the weights do not change).
+struct FwdExt {
+  const float* inl = nullptr;   // bordered channels-last input [B][H+3][W+3][C]; nullptr: made here from `input`
+  const float* wt = nullptr;    // weights in the forward kernel's layout; nullptr: re-laid-out here from `weight`
+  int out_nhwc = 0, out_pix_pitch = 0, out_row_pitch = 0, act = 0;
+  long long out_img_pitch = 0;
+  float slope = 0.0f;
+};
+
 int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, const float* bias, const float* offset,
                 const float* mask, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
-                int dh, int dw, int dg, float* output, void* workspace, size_t workspace_bytes, bool want_bf16) {
-  if (!input || !weight || !bias || !offset || !mask || !output) return C2M_ERR_INVALID_ARG;
+                int dh, int dw, int dg, float* output, void* workspace, size_t workspace_bytes, bool want_bf16,
+                const FwdExt& ext = FwdExt()) {
+  if ((!input && !ext.inl) || (!weight && !ext.wt) || !bias || !offset || !mask || !output) return C2M_ERR_INVALID_ARG;
   Geom g;
   int rc = make_geom(g, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg);
   if (rc != C2M_OK) return rc;
   if (g.CPG % 2 != 0) return C2M_ERR_UNSUPPORTED;  // k-pairs of the fp32 MFMA never straddle a (group, tap)
   g.CoPad = copad_fwd(Co);
   const bool nhwc = use_nhwc(g);
-  const size_t wbytes = align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
-  const size_t need = wbytes + (nhwc ? align256(sizeof(float) * (size_t)B * C * (H + 3) * (W + 3)) : 0);
-  if (!workspace || workspace_bytes < need) return C2M_ERR_WORKSPACE;
+  if ((ext.inl || ext.wt || ext.out_nhwc) && (!nhwc || want_bf16)) return C2M_ERR_UNSUPPORTED;
+  if (ext.out_nhwc && (Co % 4 != 0 || ext.out_pix_pitch % 4 != 0 || ext.out_row_pitch % 4 != 0 || ext.out_img_pitch % 4 != 0 ||
+                       ((uintptr_t)output & 15)))
+    return C2M_ERR_UNSUPPORTED;
+  g.out_nhwc = ext.out_nhwc; g.out_pix_pitch = ext.out_pix_pitch; g.out_row_pitch = ext.out_row_pitch;
+  g.out_img_pitch = ext.out_img_pitch; g.act = ext.act; g.slope = ext.slope;
+  const size_t wbytes = ext.wt ? 0 : align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
+  const size_t need = wbytes + ((nhwc && !ext.inl) ? align256(sizeof(float) * (size_t)B * C * (H + 3) * (W + 3)) : 0);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return C2M_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
-  float* wt = static_cast<float*>(workspace);
-  float* inl = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
+  float* wt = ext.wt ? const_cast<float*>(ext.wt) : static_cast<float*>(workspace);
+  float* inl = ext.inl ? const_cast<float*>(ext.inl) : reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
   // 8-channel groups are processed as virtual groups of two (see SPLITG): the kernel and the weight re-layout see the
   // virtual grouping, which leaves the K order a plain (tap, group, kk) order over real channels.  (Measured, B=16: large
   // layer 16.4 -> 13.7 ms on random flows, 7.6 -> 7.1 ms on coherent ones; 16-channel groups lose 2-10 %, so they stay.)
@@ -1263,16 +1311,18 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
   if (split) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
   // bf16 MFMA variant: channels-last geometries whose half-run is a multiple of 8 channels; anything else computes in fp32
   const bool bf16 = want_bf16 && nhwc && gk.CPG >= 16;
-  if (nhwc) {
+  if (nhwc && !ext.inl) {
     if (bf16) launch_nhwc_copy(st, input, B, C, H, W, reinterpret_cast<__bf16*>(inl));
     else launch_nhwc_copy(st, input, B, C, H, W, inl);
   }
-  if (bf16)
-    hipLaunchKernelGGL(dcn::weight_relayout_bf16_kernel, dim3(ceil_div(g.CoPad * g.Ktot, 256)), dim3(256), 0, st, weight, gk,
-                       reinterpret_cast<__bf16*>(wt));
-  else
-    hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, gk, 0,
-                       nhwc ? 1 : 0, wt, (float*)nullptr);
+  if (!ext.wt) {
+    if (bf16)
+      hipLaunchKernelGGL(dcn::weight_relayout_bf16_kernel, dim3(ceil_div(g.CoPad * g.Ktot, 256)), dim3(256), 0, st, weight, gk,
+                         reinterpret_cast<__bf16*>(wt));
+    else
+      hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, st, weight, gk, 0,
+                         nhwc ? 1 : 0, wt, (float*)nullptr);
+  }
   if ((rc = check_launch()) != C2M_OK) return rc;
   if (nhwc) {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
@@ -1302,6 +1352,45 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
   return check_launch();
 }
 }  // namespace
+
+extern "C" int c2m_nchw_to_nhwc_bordered_f32(c2m_stream_t stream, const float* input, int B, int C, int H, int W, float* out) {
+  if (!input || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return C2M_ERR_INVALID_ARG;
+  launch_nhwc_copy(as_stream(stream), input, B, C, H, W, out);
+  return check_launch();
+}
+
+extern "C" size_t c2m_dcn_v2_relayout_bytes(int C, int Co, int kh, int kw, int dg) {
+  Geom g;
+  if (make_geom(g, 1, C, 8, 8, Co, kh, kw, 1, 1, kh / 2, kw / 2, 1, 1, dg) != C2M_OK || !use_nhwc(g)) return 0;
+  return sizeof(float) * (size_t)g.KtotPad * copad_fwd(Co);
+}
+
+extern "C" int c2m_dcn_v2_relayout_f32(c2m_stream_t stream, const float* weight, int C, int Co, int kh, int kw, int dg,
+                                       float* wt) {
+  if (!weight || !wt) return C2M_ERR_INVALID_ARG;
+  Geom g;
+  int rc = make_geom(g, 1, C, 8, 8, Co, kh, kw, 1, 1, kh / 2, kw / 2, 1, 1, dg);
+  if (rc != C2M_OK) return rc;
+  if (!use_nhwc(g)) return C2M_ERR_UNSUPPORTED;
+  g.CoPad = copad_fwd(Co);
+  Geom gk = g;
+  if (g.CPG == 8 && g.dg % 4 == 0) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
+  hipLaunchKernelGGL(dcn::weight_relayout_kernel, dim3(ceil_div(g.CoPad * g.KtotPad, 256)), dim3(256), 0, as_stream(stream),
+                     weight, gk, 0, 1, wt, (float*)nullptr);
+  return check_launch();
+}
+
+extern "C" int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* input_bordered, const float* wt,
+                                           const float* bias, const float* offset, const float* mask, int B, int C, int H,
+                                           int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                           int dg, float* output, int out_nhwc, int out_pix_pitch, int out_row_pitch,
+                                           long long out_img_pitch, int act, float slope) {
+  FwdExt ext;
+  ext.inl = input_bordered; ext.wt = wt; ext.out_nhwc = out_nhwc; ext.out_pix_pitch = out_pix_pitch;
+  ext.out_row_pitch = out_row_pitch; ext.out_img_pitch = out_img_pitch; ext.act = act; ext.slope = slope;
+  return dcn_forward(stream, nullptr, nullptr, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
+                     nullptr, 0, false, ext);
+}
 
 extern "C" int c2m_dcn_v2_forward_f32(c2m_stream_t stream, const float* input, const float* weight, const float* bias,
                                       const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh,

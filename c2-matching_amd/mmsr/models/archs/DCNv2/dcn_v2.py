@@ -84,6 +84,16 @@ class _FusedOffsets(Function):
         return torch.cat((g_offset, g_mask * mask * (1 - mask)), dim=1), None, None, None, None
 
 
+class FusedPreOffset:
+    """Argument of the fused inference path of ``DCN_sep_pre_multi_offset`` in place of the ``pre_offset`` tensor: the
+    un-padded flow map of the arg-max indices (``c2m_amd.ops.index_to_flow``, [B, h-2, w-2, 2]) + the scale of this layer
+    (H / h = 1, 2, 4); the offset/mask head kernel synthesises the [B, 9, H, W, 2] pre-offsets from it on the fly.
+    ``lrelu_slope``: fold the LeakyReLU that follows every DynAgg (ref_restoration_arch.py:152-154) into the output."""
+
+    def __init__(self, flow, scale, lrelu_slope=None):
+        self.flow, self.scale, self.lrelu_slope = flow, int(scale), lrelu_slope
+
+
 class _OffsetMeanWatch:
     """Deferred version of the reference's `offset_mean > 100` check: no host sync inside forward."""
 
@@ -247,11 +257,29 @@ class DCN_sep_pre_multi_offset(_SelfOffsetDCN):
         Args:
             pre_offset: precomputed_offset. Size: [b, 9, h, w, 2], last dim (x, y)
         '''
+        if isinstance(pre_offset, FusedPreOffset):
+            return self._forward_fused(x[0], x[1], pre_offset)
         feat = x
         if self.extra_offset_mask:
             x, feat = x[0], x[1]   # x = [input, features]
         offset, mask = self._offset_and_mask(feat, pre_offset, watch=True)
         return self._conv(x, offset, mask)
+
+    @torch.no_grad()
+    def _forward_fused(self, ref, feat, pre):
+        """Inference on the channels-last kernels.  ref: c2m_amd.ops.BorderedNHWC of the feature to warp (shared with the
+        caller's offset convolutions); feat: channels-last offset feature; -> channels-last output.  One launch for the
+        head (conv + bias + pre-offset synthesis + sigmoid + the warning's |offset| sum), one for the warp."""
+        if self.kernel_size != (3, 3) or self.stride != (1, 1) or self.padding != (1, 1) or self.dilation != (1, 1):
+            raise NotImplementedError('fused DynAgg path: 3x3 / stride 1 / pad 1 only')
+        head = self.conv_offset_mask
+        self._watch.poll()
+        abs_sum = torch.zeros(_ABS_SLOTS, dtype=torch.float64, device=feat.device)
+        offset, mask = _ops.conv3x3_dcn_head(feat, head.weight, head.bias, self.deformable_groups, pre.flow, pre.scale, abs_sum)
+        self._watch.push(abs_sum, offset.numel())
+        act = _ops.ACT_NONE if pre.lrelu_slope is None else _ops.ACT_LRELU
+        return _ops.dcn_v2_forward_nhwc(ref, self.weight, self.bias, offset, mask, self.deformable_groups, act=act,
+                                        slope=pre.lrelu_slope or 0.0)
 
 
 class _NotOnThisPath(nn.Module):

@@ -18,6 +18,57 @@ from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
 logger = logging.getLogger('base')
 
 
+class PreOffsets(dict):
+    """The ``pre_offset`` dict of the reference (keys relu3_1 / relu2_1 / relu1_1 -> [B, 9, s*h, s*w, 2] float32, last dim
+    (x, y), s = 1 / 2 / 4; corres_generation_arch.py:69-109), built LAZILY from the arg-max index map.
+
+    Any consumer that indexes it gets exactly the reference's tensors (one kernel launch per scale on first access).  The
+    fused decoder path of ``RestorationNet`` never does: it hands ``flow`` (index_to_flow of the whole batch, [B,h-2,w-2,2])
+    to the DCN offset/mask head kernel, which synthesises the shifted / up-scaled / repeated offsets on the fly -- the
+    three tensors (59 + 236 + 944 MB at batch 16, LR 160) are then never materialised."""
+
+    _SCALE = {'relu3_1': 1, 'relu2_1': 2, 'relu1_1': 4}
+
+    def __init__(self, max_idx, h, w):
+        super().__init__()
+        self.max_idx, self.h, self.w = max_idx, int(h), int(w)
+        self._flow = None
+
+    @property
+    def flow(self):
+        if self._flow is None:
+            self._flow = _ops.index_to_flow(self.max_idx)
+        return self._flow
+
+    def __missing__(self, key):
+        if key not in self._SCALE:
+            raise KeyError(key)
+        (t,) = _ops.build_pre_offsets(self.max_idx, self.h, self.w, scales=(self._SCALE[key],))
+        self[key] = t
+        return t
+
+    def __contains__(self, key):
+        return key in self._SCALE
+
+    def __iter__(self):
+        return iter(self._SCALE)
+
+    def __len__(self):
+        return len(self._SCALE)
+
+    def keys(self):
+        return self._SCALE.keys()
+
+    def values(self):
+        return [self[k] for k in self._SCALE]
+
+    def items(self):
+        return [(k, self[k]) for k in self._SCALE]
+
+    def get(self, key, default=None):
+        return self[key] if key in self._SCALE else default
+
+
 class CorrespondenceGenerationArch(nn.Module):
 
     def __init__(self, patch_size=3, stride=1, vgg_layer_list=['relu3_1', 'relu2_1', 'relu1_1'], vgg_type='vgg19'):
@@ -49,8 +100,7 @@ class CorrespondenceGenerationArch(nn.Module):
             raise NotImplementedError('pre-offset generation is defined for patch_size=3, stride=1')
         h, w = dense_features['dense_features1'].shape[2:]
         max_idx, _ = self.match(dense_features)
-        off3, off2, off1 = _ops.build_pre_offsets(max_idx, h, w)
-        # size: [b, 9, h, w, 2], the order of the last dim: [x, y]
-        pre_offset = {'relu1_1': off1, 'relu2_1': off2, 'relu3_1': off3}
+        # size: [b, 9, h, w, 2], the order of the last dim: [x, y] -- materialised on first access, see PreOffsets
+        pre_offset = PreOffsets(max_idx, h, w)
         img_ref_feat = self.vgg(img_ref_hr)
         return pre_offset, img_ref_feat

@@ -1,12 +1,26 @@
 """``RestorationNet`` (ref_restoration_arch.py:30-65) with the reference's parameter names (checkpoint keys listed in
 SURVEY.md A.3).  The three ``*_dyn_agg`` sites are DCN_sep_pre_multi_offset layers (:77-85, :101-109, :124-132) and run
-on the gfx950 DCNv2 kernels; the plain 3x3 convolutions / residual blocks / pixel shuffles stay stock torch (MIOpen)."""
+on the gfx950 DCNv2 kernels.
+
+Two execution paths over the SAME modules / parameters:
+
+* autograd (training, or any call with gradients enabled): module by module as the reference composes them, the plain
+  3x3 convolutions on stock torch (MIOpen), DynAgg through ``_DCNv2`` with the hand-written forward/backward kernels;
+* fused inference (``torch.no_grad()``, fp32 on the GPU, ``pre_offset`` produced by this package's
+  ``CorrespondenceGenerationArch``): the whole net runs channels-last on the hand-written gfx950 kernels --
+  csrc/conv3x3.hip computes act(conv(cat(a, b)) + bias) + residuals in one launch per convolution (no cat / bias /
+  ReLU / add / PixelShuffle kernels, no layout changes between layers), the DCN offset/mask heads synthesise the
+  pre-offsets from the arg-max flow map, and the DCNv2 forward reads the zero-bordered channels-last copy of the Ref
+  feature that the offset convolutions already use and writes channels-last with its LeakyReLU folded in.
+"""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 import mmsr.models.archs.arch_util as arch_util
+from c2m_amd import ops as _ops
 from mmsr.models.archs.DCNv2.dcn_v2 import DCN_sep_pre_multi_offset as DynAgg
+from mmsr.models.archs.DCNv2.dcn_v2 import FusedPreOffset
 
 
 class ContentExtractor(nn.Module):
@@ -20,6 +34,29 @@ class ContentExtractor(nn.Module):
 
     def forward(self, x):
         return self.body(self.lrelu(self.conv_first(x)))
+
+    def forward_fused(self, x):
+        """x [B,3,h,w] (any layout) -> content feature, channels-last.  conv_first sees the image zero-padded to 32
+        channels (the kernel's chunk size; the weights are padded to match)."""
+        B, C, H, W = x.shape
+        x32 = torch.zeros((B, 32, H, W), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        x32[:, :C] = x
+        f = _ops.conv3x3(x32, self.conv_first.weight, self.conv_first.bias, act=_ops.ACT_LRELU, slope=0.1)
+        return _fused_body(self.body, f)
+
+
+def _fusable_body(body):
+    return all(isinstance(b, arch_util.ResidualBlockNoBN) and b.res_scale == 1 for b in body)
+
+
+def _fused_body(body, f, skip=None):
+    """16 x (x + conv2(relu(conv1(x)))) (arch_util.py:128-136), two launches per block; `skip` (the stage input,
+    ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue."""
+    n = len(body)
+    for k, blk in enumerate(body):
+        t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU)
+        f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None)
+    return f
 
 
 class DynamicAggregationRestoration(nn.Module):
@@ -62,6 +99,33 @@ class DynamicAggregationRestoration(nn.Module):
             x = self._stage(name, x, img_ref_feat[key], pre_offset[key])
         return x
 
+    def _stage_fused(self, name, x, ref_feat, flow, scale):
+        lrelu = dict(act=_ops.ACT_LRELU, slope=0.1)
+        ref = _ops.BorderedNHWC(ref_feat)          # one copy serves the offset conv (as a source) and the DCN gathers
+        c1, c2 = getattr(self, f'{name}_offset_conv1'), getattr(self, f'{name}_offset_conv2')
+        of = _ops.conv3x3([x, ref.interior()], c1.weight, c1.bias, **lrelu)
+        of = _ops.conv3x3(of, c2.weight, c2.bias, **lrelu)
+        # (a module call, so forward hooks see the DynAgg boundary on this path too)
+        swapped = getattr(self, f'{name}_dyn_agg')([ref, of], FusedPreOffset(flow, scale, lrelu_slope=0.1))
+        hd = getattr(self, f'head_{name}')[0]
+        h = _ops.conv3x3([x, swapped], hd.weight, hd.bias, **lrelu)
+        h = _fused_body(getattr(self, f'body_{name}'), h, skip=x)
+        tail = getattr(self, f'tail_{name}')
+        if name == 'large':
+            t = _ops.conv3x3(h, tail[0].weight, tail[0].bias, **lrelu)
+            return _ops.conv3x3(t, tail[2].weight, tail[2].bias, out_mode='nchw')
+        # conv -> PixelShuffle(2) -> lrelu == conv -> lrelu -> PixelShuffle(2) (elementwise), done in the epilogue
+        return _ops.conv3x3(h, tail[0].weight, tail[0].bias, out_mode='pixel_shuffle', **lrelu)
+
+    def forward_fused(self, x, flow, img_ref_feat):
+        for (name, key, _), scale in zip(self._STAGES, (1, 2, 4)):
+            x = self._stage_fused(name, x, img_ref_feat[key], flow, scale)
+        return x
+
+    def fusable(self):
+        return all(_fusable_body(getattr(self, f'body_{n}')) and getattr(self, f'{n}_dyn_agg').deformable_groups == 8
+                   for n, _, _ in self._STAGES)
+
 
 class RestorationNet(nn.Module):
 
@@ -78,8 +142,21 @@ class RestorationNet(nn.Module):
             head.weight.data.zero_()
             head.bias.data.zero_()
 
+    def _use_fused(self, x, pre_offset, img_ref_feat):
+        from mmsr.models.archs.corres_generation_arch import PreOffsets
+        if torch.is_grad_enabled() or not isinstance(pre_offset, PreOffsets) or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        if torch.is_autocast_enabled('cuda'):   # reduced-precision inference (BASELINE configs[4]) keeps the bf16 convs
+            return False
+        ok_feats = all(img_ref_feat[k].dtype == torch.float32 and img_ref_feat[k].shape[1] == c
+                       for _, k, c in DynamicAggregationRestoration._STAGES)
+        return ok_feats and _fusable_body(self.content_extractor.body) and self.dyn_agg_restore.fusable()
+
     def forward(self, x, pre_offset, img_ref_feat):
         """x: LR image [B,3,h,w]; pre_offset / img_ref_feat: dicts keyed relu3_1 / relu2_1 / relu1_1."""
         base = F.interpolate(x, None, 4, 'bilinear', False)
+        if self._use_fused(x, pre_offset, img_ref_feat):
+            content_feat = self.content_extractor.forward_fused(x)
+            return self.dyn_agg_restore.forward_fused(content_feat, pre_offset.flow, img_ref_feat) + base
         content_feat = self.content_extractor(x)
         return self.dyn_agg_restore(content_feat, pre_offset, img_ref_feat) + base

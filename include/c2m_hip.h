@@ -55,7 +55,8 @@ int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device,
  * kernel ids (C2M_KERNEL_*) and clears the list.  Off by default; costs two event records per call when on.
  */
 enum { C2M_KERNEL_CORR_MFMA = 1, C2M_KERNEL_CORR_GENERIC = 2, C2M_KERNEL_DCN_FWD = 3, C2M_KERNEL_DCN_BWD_DATA = 4,
-       C2M_KERNEL_DCN_BWD_WEIGHT = 5 };
+       C2M_KERNEL_DCN_BWD_WEIGHT = 5, C2M_KERNEL_CONV3X3 = 6 };
+enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LEAKY_RELU = 2 };   /* fused activations of the decoder-path entry points */
 int c2m_profile_enable(int on);
 int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
 
@@ -111,6 +112,28 @@ int c2m_dcn_v2_forward_bf16mma_f32(c2m_stream_t stream, const float* input, cons
                                    int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output,
                                    void* workspace, size_t workspace_bytes);
 
+/*
+ * Fused decoder path (inference): the same forward operator with the per-call preparation hoisted out of it.
+ *   c2m_nchw_to_nhwc_bordered_f32   input [B][C][H][W] -> zero-bordered channels-last copy [B][H+3][W+3][C] (1 pixel
+ *                                   top/left, 2 bottom/right).  It is what the forward kernel gathers from; pixel (0,0)
+ *                                   sits at out + ((W+3) + 1) * C, so the copy doubles as a c2m_conv_src (pix_pitch C,
+ *                                   row_pitch (W+3)*C, img_pitch (H+3)*(W+3)*C) for the offset convolutions.
+ *   c2m_dcn_v2_relayout_f32         weight [Co][C][kh][kw] -> the kernel's A-operand layout (cache it while the weights
+ *                                   do not change); c2m_dcn_v2_relayout_bytes == 0: geometry not on the channels-last path
+ *                                   (8/16/32 channels per group and an even group count are).
+ *   c2m_dcn_v2_forward_nhwc_f32     dcn_v2_cuda_forward (dcn_v2_cuda.cu:42-172) from those two; output planar
+ *                                   [B][Co][Ho][Wo] (out_nhwc = 0) or channels-last with the given pitches (in floats)
+ *                                   and an optional fused activation (C2M_ACT_*: the lrelu that follows every DynAgg,
+ *                                   ref_restoration_arch.py:152-154).
+ */
+int c2m_nchw_to_nhwc_bordered_f32(c2m_stream_t stream, const float* input, int B, int C, int H, int W, float* out);
+size_t c2m_dcn_v2_relayout_bytes(int C, int Co, int kh, int kw, int dg);
+int c2m_dcn_v2_relayout_f32(c2m_stream_t stream, const float* weight, int C, int Co, int kh, int kw, int dg, float* wt);
+int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* input_bordered, const float* wt, const float* bias,
+                                const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh, int kw,
+                                int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output, int out_nhwc,
+                                int out_pix_pitch, int out_row_pitch, long long out_img_pitch, int act, float slope);
+
 size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                                            int pw, int dh, int dw, int dg);
 /* All gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255).  grad_input may be NULL:
@@ -132,6 +155,63 @@ int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, const float
 #define C2M_ABS_SUM_SLOTS 256
 int c2m_dcn_fuse_offsets_f32(c2m_stream_t stream, const float* conv_out, const float* pre_offset, int B, int dg, int K,
                              int H, int W, float* offset, float* mask, double* abs_sum);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution, fp32, channels-last, fused epilogue
+ *
+ *   out = act( conv3x3( cat(src[0], src[1]) ) + bias ) + res1 + res2
+ *
+ * replaces, per call, one nn.Conv2d of the decoder (mmsr/models/archs/ref_restoration_arch.py:140-187,
+ * arch_util.py:80-136) TOGETHER with the elementwise ops the reference runs around it: torch.cat of the two inputs
+ * (:147,:151 ...), the bias add, ReLU / LeakyReLU, the residual adds, nn.PixelShuffle(2) (out_mode 1), and -- for the
+ * DCN offset/mask head (out_mode 3) -- chunk/cat/sigmoid of mmsr/models/archs/DCNv2/dcn_v2.py:229-245 plus the pre-offset
+ * construction of corres_generation_arch.py:29-46,69-109 (index_to_flow, 9 tensor_shift copies, x s, repeat over groups,
+ * (x,y)->(y,x)), synthesised from the flow map of the arg-max indices instead of being read from [B,9,H,W,2] tensors.
+ *
+ * Sources are channels-last with explicit pitches (in floats), so a torch channels_last tensor, a channel slice of one,
+ * or the zero-bordered copy made by c2m_nchw_to_nhwc_bordered_f32 can be passed without a copy.  Every source must bring
+ * a multiple of 32 channels; pitches and base pointers must be multiples of 4 floats (16-byte LDS-DMA pieces).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct c2m_conv_src {
+  const float* ptr;      /* pixel (0,0), channel 0, sample 0 */
+  int C;                 /* channels taken from this source */
+  int pix_pitch;         /* floats between horizontally adjacent pixels (= total channels of the tensor) */
+  int row_pitch;         /* floats between rows */
+  long long img_pitch;   /* floats between samples */
+} c2m_conv_src;
+
+enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3 };
+
+typedef struct c2m_conv3x3_desc {
+  int B, H, W, Cin, Cout;
+  int nsrc;                /* 1 or 2; Cin = sum of src[].C */
+  c2m_conv_src src[2];
+  const float* wr;         /* weights re-laid-out by c2m_conv3x3_relayout_f32 (cache it while the weights do not change) */
+  const float* bias;       /* [Cout] or NULL */
+  int act;                 /* C2M_ACT_* (applied before the residual adds; ignored by C2M_OUT_DCN_HEAD) */
+  float slope;             /* LeakyReLU negative slope */
+  int out_mode;            /* C2M_OUT_* */
+  float* out;              /* NHWC: pitches below.  PIXEL_SHUFFLE2: [B][2H][2W][Cout/4] with the pitches below.
+                              NCHW: [B][Cout][H][W].  DCN_HEAD: offset [B][n_off][H][W] (raw + pre-offset, (dy,dx) pairs) */
+  int out_pix_pitch, out_row_pitch;
+  long long out_img_pitch;
+  const float* res1;       /* NHWC only: tensors with out's geometry added after the activation, or NULL */
+  const float* res2;
+  float* mask_out;         /* DCN_HEAD: [B][Cout - n_off][H][W] = sigmoid(logits) */
+  const float* flow;       /* DCN_HEAD: [B][fh][fw][2] (x,y) from c2m_index_to_flow_f32, or NULL for "no pre-offset" */
+  int fh, fw;              /* = h-2, w-2 of the matched feature maps */
+  int scale;               /* H / h: 1, 2 or 4 */
+  int n_off;               /* offset channels = 2 * deformable_groups * 9 */
+  double* abs_sum;         /* DCN_HEAD: C2M_ABS_SUM_SLOTS partial sums of |raw offset| (caller zeroes), or NULL */
+} c2m_conv3x3_desc;
+
+size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */
+int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight /* [Cout][Cin][3][3] */, int Cin, int Cout, float* wr);
+int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
+
+/* max_idx [B][hq][wq] int64 -> flow [B][hq][wq][2] fp32 (x, y) = (idx % wq - x, idx / wq - y): index_to_flow of
+ * corres_generation_arch.py:29-46 for the whole batch, without the zero padding (the consumer bounds-checks). */
+int c2m_index_to_flow_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int hq, int wq, float* flow);
 
 #ifdef __cplusplus
 }

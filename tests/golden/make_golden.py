@@ -137,11 +137,16 @@ def fill_parameters(module, prefix):
     module.load_state_dict(sd)
 
 
+def restoration_index_map(B, h, w):
+    """The hashed arg-max index map [B, h-2, w-2] the restoration fixture's pre-offsets are built from."""
+    hp, wp = h - 2, w - 2
+    return (synth.uniform((B, hp, wp), 1001, 0.0, 1.0).astype(np.float64) * (hp * wp)).astype(np.int64) % (hp * wp)
+
+
 def restoration_inputs(B, h, w):
     """LR image, pre-offset dict and ref-feature dict for RestorationNet at LR size h x w."""
     lr = synth.uniform((B, 3, h, w), 1000, 0.0, 1.0)
-    hp, wp = h - 2, w - 2
-    idx = (synth.uniform((B, hp, wp), 1001, 0.0, 1.0).astype(np.float64) * (hp * wp)).astype(np.int64) % (hp * wp)
+    idx = restoration_index_map(B, h, w)
     offs = [oracle.build_pre_offsets(idx[b], h, w) for b in range(B)]
     pre = {"relu3_1": np.stack([o[0] for o in offs]), "relu2_1": np.stack([o[1] for o in offs]),
            "relu1_1": np.stack([o[2] for o in offs])}

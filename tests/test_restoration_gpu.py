@@ -35,6 +35,22 @@ def test_restoration_net_matches_reference_golden(dev, golden_dir):
         assert err < 5e-5, f"DynAgg {stage}: {err}"
     err = float(np.abs(sr.cpu().numpy() - gold["sr"]).max())
     assert err < 5e-5, f"SR max abs err {err}"
+    # the fused inference path (channels-last conv3x3 / DCN-head / DCNv2 kernels, pre-offsets synthesised from the index map
+    # the fixture's pre-offset tensors were built from) against the same golden
+    from make_golden import restoration_index_map
+    from mmsr.models.archs.corres_generation_arch import PreOffsets
+    lazy = PreOffsets(t(restoration_index_map(1, 40, 40)), 40, 40)
+    taps.clear()
+    with torch.no_grad():
+        assert net._use_fused(t(lr), lazy, {k: t(v) for k, v in feats.items()})
+        sr_f = net(t(lr), lazy, {k: t(v) for k, v in feats.items()})
+    for stage in ("small", "medium", "large"):   # hook output on this path = lrelu(DynAgg): undo it (slope 0.1, exact sign)
+        got = np.where(taps[stage] > 0, taps[stage], taps[stage] / np.float32(0.1))
+        err = float(np.abs(got - gold[f"dyn_agg_{stage}"]).max())
+        assert err < 5e-5, f"fused DynAgg {stage}: {err}"
+    err = float(np.abs(sr_f.cpu().numpy() - gold["sr"]).max())
+    assert err < 5e-5, f"fused path SR max abs err {err}"
+    assert np.array_equal(lazy["relu2_1"].cpu().numpy(), pre["relu2_1"])   # the lazy dict still yields the reference's tensors
 
 
 def _build_chain(dev):
@@ -149,6 +165,7 @@ def test_stage3_training_step_runs_and_learns(dev):
 # fused internally: the expected value is conv_offset_mask (torch fp64 on the CPU) -> the offset/mask assembly of
 # dcn_v2.py:229-245 in numpy -> oracle.dcn_v2_forward.
 # ---------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
 def _dynagg_expected(oracle, module, ref_feat, offset_feat, pre_offset, b):
     """Oracle value of one DynAgg call for sample b: (out [Co,H,W], offset, mask)."""
     dg, K = module.deformable_groups, 9
@@ -173,8 +190,10 @@ def _hook_dynagg(net, store, keep_grad=False):
 
         def hook(m, args, out, stage=stage):
             (x, pre) = args
-            store[stage] = {"ref": x[0].detach(), "feat": x[1].detach(), "pre": pre.detach() if torch.is_tensor(pre) else pre,
-                            "out": out.detach()}
+            fused = not torch.is_tensor(pre)          # FusedPreOffset: x[0] is a BorderedNHWC, out = lrelu(DynAgg)
+            ref = x[0].interior() if fused else x[0]
+            store[stage] = {"ref": ref.detach(), "feat": x[1].detach(), "pre": None if fused else pre.detach(),
+                            "out": out.detach(), "lrelu": pre.lrelu_slope if fused else None}
             if keep_grad and out.requires_grad:
                 out.register_hook(lambda g, stage=stage: store[stage].__setitem__("gout", g.detach()))
         mod.register_forward_hook(hook)
@@ -219,13 +238,21 @@ def test_cfg3_chain_160_batch2(dev):
     assert np.array_equal(pre["relu3_1"][b].cpu().numpy(), o3)
     assert np.array_equal(pre["relu2_1"][b].cpu().numpy(), o2)
     assert np.array_equal(pre["relu1_1"][b].cpu().numpy(), o1)
-    for stage in ("small", "medium", "large"):
+    with torch.no_grad():
+        assert g._use_fused(lq, pre, ref_feat)   # this chain runs the fused channels-last path
+    for stage, key in (("small", "relu3_1"), ("medium", "relu2_1"), ("large", "relu1_1")):
         t = taps[stage]
         mod = getattr(g.dyn_agg_restore, f"{stage}_dyn_agg")
-        want, _, _ = _dynagg_expected(oracle, mod, t["ref"], t["feat"], t["pre"], b)
+        want, _, _ = _dynagg_expected(oracle, mod, t["ref"], t["feat"], pre[key], b)
+        if t["lrelu"] is not None:
+            want = np.where(want > 0, want, want * np.float32(t["lrelu"]))
         got = t["out"][b].cpu().numpy()
         err = float(np.abs(got - want).max())
         assert err < 1e-4 * max(1.0, float(np.abs(want).max())), f"DynAgg {stage} at LR 160: {err}"
+    # the autograd-capable module-by-module path (stock convolutions, materialised pre-offset tensors) gives the same image
+    with torch.no_grad():
+        sr_stock = g(lq, {k: pre[k] for k in pre}, ref_feat)
+    assert float((sr_stock - sr).abs().max()) < 1e-3   # north_star's bound on SR pixels
     # samples of a batch are independent: sample 1 alone gives the same SR image
     with torch.no_grad():
         feats1 = ext(up[1:], ref[1:])
