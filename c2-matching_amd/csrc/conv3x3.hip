@@ -34,6 +34,8 @@
 // waits at its barrier the other owns the matrix pipes.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "c2m_common.h"
 
 namespace c2m {
@@ -76,7 +78,6 @@ struct Params {
   int fh, fw, scale, n_off;   // n_off = 2*dg*9 offset channels (the rest are mask logits)
   double* abs_sum;       // mode 3: C2M_ABS_SUM_SLOTS partial sums of |raw offset| or nullptr
   int out_vec4;          // mode 0: out / res pitches and bases are 16-byte aligned -> float4 stores
-  int stagger;           // start-up delay (x 8192 cycles) of the workgroups in odd CU slots, see conv3x3_kernel
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -111,20 +112,24 @@ __global__ void __launch_bounds__(256) index_to_flow_kernel(const int64_t* __res
   flow[i] = make_float2((float)((int)(idx % wq) - x), (float)((int)(idx / wq) - y));
 }
 
-__device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
-  return *(const __attribute__((address_space(3))) f32x4*)byte_addr;
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MT>
+// raw buffer descriptor (stride 0, bounds-checked: a lane whose offset lies beyond num_records reads zeros -- that is how the
+// zero padding of the halo tile is produced, without a select per lane)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr unsigned kOOB = 0x80000000u;   // voffset of a lane that must read zeros (>= any num_records used here)
+
+// MODE = Params::out_mode (compile time: each store flavour is its own kernel, the others' code is not even loaded)
+template <int MT, int MODE>
 __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   constexpr int MW = 32 * MT;
   constexpr int WSLOT = MW * 128;          // bytes of one unit's weight image
-  constexpr int NW_W = MT;                 // weight DMA instructions per wave and unit (MT KiB each)
+  constexpr int NW_W = MT;                 // weight DMA instructions per wave and unit (1 KiB each)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   // [in0 | in1 | w ring x3 | dummy 1 KiB]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address
@@ -138,141 +143,205 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
   const int x0 = tx * TW, y0 = ty * TH;
   const int U = p.nchunks * 9;
-  const float* zero = p.wr + p.wr_zero_off;
 
-  // Two workgroups share a CU (one wave each per SIMD).  Started together they run in lockstep -- same barriers, same
-  // prologue / epilogue at the same time -- and the matrix pipe idles whenever both stall.  Delaying the workgroup in
-  // the odd slot once puts the pair in anti-phase for the rest of the launch (each slot's successors inherit the offset):
-  // one's DMA prologue, barrier waits and store epilogue then run under the other's MFMAs.
-  if (p.stagger > 0) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (((hwid >> 16) & 1) && blockIdx.x < 512 && blockIdx.y == 0)   // TG_ID = the workgroup's slot on its CU; first dispatch round only
-      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-  }
+  // ------------------------------------------------------------------------------------------------------------------
+  // DMA plumbing.  Every operand byte travels global -> LDS by buffer_load_dwordx4 ... lds (1 KiB per wave-instruction:
+  // LDS address = wave-uniform M0 base + lane * 16, global address = descriptor base + SGPR offset + per-lane VGPR offset).
+  //   weights : unit u of this cout block is one linear image of WSLOT bytes: voffset = (instr * 64 + lane) * 16,
+  //             soffset = u * WSLOT.  No VALU per unit.
+  //   halo    : instruction n (64 pieces of 16 B) is issued by wave n & 3 as its slot n >> 2; piece P = 64n + lane is pixel
+  //             pl = P >> 3 of the 34 x 6 tile, LDS slot P & 7, logical piece q = slot ^ ((pl >> 1) & 7) (channels 4q..4q+3
+  //             of the chunk).  voffset = byte offset of (pixel, 4q) inside the sample, or kOOB outside the image / tile;
+  //             soffset = the chunk's channel offset.  The 7 voffsets are computed once per source tensor.
+  // ------------------------------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * U * (MW * 32), (unsigned)U * WSLOT);
+  const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
+  auto issue_w = [&](int u) __attribute__((always_inline)) {
+    const unsigned dst = w_base + (u % 3) * WSLOT + wv * NW_W * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 0, 0);
+    if constexpr (NW_W == 2)   // the instruction offset advances BOTH the global and the LDS address
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 1024, 0);
+  };
 
-  // halo-tile DMA: instruction n (64 pieces of 16 B) is issued by wave n & 3 as its slot n >> 2; piece P = 64n + lane is
-  // pixel pl = P >> 3, LDS slot P & 7, logical piece q = slot ^ ((pl >> 1) & 7)
-  int pyx[NIN_W];   // (iy << 16) | ix of the source pixel, -1 = outside the image / beyond the tile (reads the zero page)
+  unsigned ivoff[NIN_W];
+  auto set_source = [&](const Src& S) __attribute__((always_inline)) {
+    int ry = 0, rx = 8 * wv + (l >> 3);   // pixel of slot 0 (< 34: row 0 of the halo tile); each further slot is 32 pixels on
 #pragma unroll
-  for (int s = 0; s < NIN_W; ++s) {
-    const int n = wv + 4 * s;
-    const int pl = 8 * n + (l >> 3);
-    const int ry = pl / HW_, rx = pl - ry * HW_;
-    const int iy = y0 - 1 + ry, ix = x0 - 1 + rx;
-    const bool ok = n < NIN_REAL && pl < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    pyx[s] = ok ? ((iy << 16) | ix) : -1;
-  }
-  auto issue_in = [&](int c) {
+    for (int sl = 0; sl < NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
+      const int q = (l & 7) ^ ((4 * n + (l >> 4)) & 7);
+      const int iy = y0 - 1 + ry, ix = x0 - 1 + rx;
+      const bool ok = n < NIN_REAL && ry < HH_ && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * q) * 4u : kOOB;
+      rx += 32;
+      if (rx >= HW_) { rx -= HW_; ry += 1; }
+    }
+  };
+  auto src_rsrc = [&](const Src& S) __attribute__((always_inline)) {
+    const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
+    return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
+  };
+  const __amdgpu_buffer_rsrc_t rs0 = src_rsrc(p.src[0]), rs1 = src_rsrc(p.src[1]);
+  auto issue_in = [&](int c) __attribute__((always_inline)) {
     const int c0 = c * KCH;
     const bool first = c0 < p.src[0].C;
-    const Src& S = first ? p.src[0] : p.src[1];
-    const float* base = S.ptr + (long long)b * S.img_pitch + (first ? c0 : c0 - p.src[0].C);
+    if (c0 == 0) set_source(p.src[0]);
+    else if (c0 == p.src[0].C) set_source(p.src[1]);
     const unsigned buf = in_base + (c & 1) * IN_BYTES;
+    const int soff = (first ? c0 : c0 - p.src[0].C) * 4;
 #pragma unroll
-    for (int s = 0; s < NIN_W; ++s) {
-      const int n = wv + 4 * s;
-      const int q = (l & 7) ^ ((4 * n + (l >> 4)) & 7);
-      const int iy = pyx[s] >> 16, ix = pyx[s] & 0xffff;
-      const float* g = pyx[s] >= 0 ? base + (long long)iy * S.row_pitch + ix * S.pix_pitch + 4 * q : zero;
+    for (int sl = 0; sl < NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
       const unsigned dst = n < NIN_REAL ? buf + n * 1024 : dummy;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-  const float* wsrc = p.wr + (long long)cb * U * (MW * 32) + l * 4;
-  auto issue_w = [&](int u) {
-#pragma unroll
-    for (int k = 0; k < NW_W; ++k) {
-      const int i = wv * NW_W + k;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)u * (MW * 32) + i * 256),
-                                       (__attribute__((address_space(3))) void*)(w_base + (u % 3) * WSLOT + i * 1024),
-                                       16, 0, 0);
+      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
     }
   };
 
+  // ------------------------------------------------------------------------------------------------------------------
+  // accumulators start from the bias.  acc[mt][r] = out channel cb*MW + mt*32 + 8*(r>>2) + 4*hi + (r&3) of pixel (y, x)
+  // ------------------------------------------------------------------------------------------------------------------
+  const int y = y0 + wv, x = x0 + j;
+  const bool pok = y < p.H && x < p.W;
+  const int co_lane = cb * MW + 4 * hi;    // + mt*32 + 8*qd + e
   f32x16 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-
-  // A-operand byte offsets inside a weight slot (row = cout j of tile mt, piece 2g + hi), + mt * 4096
-  unsigned aoff[4];
+    for (int qd = 0; qd < 4; ++qd) {
+      const int co = co_lane + mt * 32 + 8 * qd;
+      f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (p.bias) {
+        if (co + 3 < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+        else
+          for (int e = 0; e < 4; ++e) bv[e] = co + e < p.Cout ? p.bias[co + e] : 0.0f;
+      }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) aoff[g] = j * 128 + (((2 * g + hi) ^ ((j >> 1) & 7)) << 4);
+      for (int e = 0; e < 4; ++e) acc[mt][4 * qd + e] = bv[e];
+    }
 
-  // prologue (issue order matters for the vmcnt waits: halo tile first, then the two weight units)
+  // A-operand byte addresses: ring slot sl, k-quad g (row = cout j of tile mt, piece 2g + hi), + mt * 4096.  Loop invariant.
+  unsigned aaddr[3][4];
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) aaddr[sl][g] = w_base + sl * WSLOT + j * 128 + (((2 * g + hi) ^ ((j >> 1) & 7)) << 4);
+
+  // Operand reads are inline asm with hand-placed s_waitcnt: hipcc's own counter tracking collapses to lgkmcnt(0) after
+  // every other k-quad here, which waits for the reads just issued for the NEXT quad (one exposed LDS latency per 8 MFMAs).
+  // LDS returns in order, so after issuing the next quad's NRD reads "lgkmcnt(NRD)" means: the current quad's have landed
+  // (scalar loads that may share the counter only make this wait longer, never shorter than needed).
+  constexpr int NRD = MT + 1;
+  // operands of (tap t, k-quad g) of the chunk whose halo tile sits at LDS address ibuf: one b128 per operand
+  auto load_ops = [&](unsigned ibuf, int t, int g, f32x4 (&a)[MT], f32x4& bq) __attribute__((always_inline)) {
+    const int dy = t / 3, dx = t - 3 * dy;
+    const int pl = (wv + dy) * HW_ + j + dx;
+    const unsigned baddr = ibuf + pl * 128 + ((((2 * g + hi) ^ (pl >> 1)) & 7) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(bq) : "v"(baddr) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aaddr[t % 3][g]) : "memory");   // 9 % 3 == 0: tap t always sits in ring slot t % 3
+    if constexpr (MT == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aaddr[t % 3][g]) : "memory");
+  };
+  // wait until at most N LDS reads are in flight; the operands are tied to the statement so that no MFMA reading them can be
+  // scheduled above it
+  auto wait_ops = [&](auto n, f32x4 (&a)[MT], f32x4& bq) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bq), "+v"(a[0]), "+v"(a[1]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq), "+v"(a[0]) : "n"(N));
+  };
+
+  // residuals (NHWC mode) are fetched at the top of the last unit: their latency runs under MFMAs, not in front of the stores
+  const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
+  f32x4 res4[MT][4];
+  const bool vec_res = MODE == 0 && p.out_vec4 && pok && (p.res1 || p.res2);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) res4[mt][qd] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // main loop.  Unit u = (chunk c, tap t).  Invariant at the top of unit u: the weight images of units u and u+1 and the
+  // halo tile of chunk c (and, from (c, 2) on, of chunk c+1) are visible to every wave; W(u+2) is in flight.  The barrier
+  // at the END of unit u publishes W(u+2) and frees ring slot u % 3 for W(u+3).  Because unit u+1's operands are visible
+  // one unit early, the last k-quad of unit u already fetches the first operands of unit u+1: MFMAs issue back to back
+  // across the barrier.
+  // ------------------------------------------------------------------------------------------------------------------
   issue_in(0);
+  if (p.nchunks > 1) issue_in(1);
   issue_w(0);
-  if (U > 1) issue_w(1);
+  issue_w(1);
+  issue_w(2);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
 
+  // two operand sets, used alternately (k-quad g of any unit reads set g & 1: 4 quads per unit keeps the parity fixed)
+  f32x4 a_s[2][MT], b_s[2];
+  load_ops(in_base, 0, 0, a_s[0], b_s[0]);
   for (int c = 0; c < p.nchunks; ++c) {
-    const unsigned ibuf = in_base + (c & 1) * IN_BYTES;
+    const unsigned ibuf = in_base + (c & 1) * IN_BYTES, ibuf_next = in_base + ((c + 1) & 1) * IN_BYTES;
     const bool more_in = c + 1 < p.nchunks;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int u = c * 9 + t;
-      // unit u needs W(u) (issued two units ago) and, at t == 0, the halo tile of chunk c (older).  Younger, still allowed
-      // in flight: W(u+1) and -- at t == 1, 2 -- the next halo tile, issued during unit (c, 0) right after W(c, 2).
-      if (u + 1 >= U) wait_vmcnt<0>();
-      else if ((t == 1 || t == 2) && more_in) wait_vmcnt<NW_W + NIN_W>();
-      else wait_vmcnt<NW_W>();
-      // bare s_barrier: __syncthreads() would add a fence = s_waitcnt vmcnt(0) and drain the DMAs that are meant to stay in
-      // flight.  This wave's shares of W(u) / the halo tile have landed (vmcnt above); the barrier publishes every wave's.
-      __builtin_amdgcn_s_barrier();
-      if (u + 2 < U) issue_w(u + 2);
-      if (t == 0 && more_in) issue_in(c + 1);
-
-      const int dy = t / 3, dx = t - 3 * dy;
-      const int pl = (wv + dy) * HW_ + j + dx;
-      const unsigned brow = ibuf + pl * 128, bsw = (pl >> 1) & 7;
-      const unsigned wslot = w_base + (t % 3) * WSLOT;   // 9 % 3 == 0: the ring position of tap t is the same in every chunk
-      f32x4 a[2][MT], bq[2];
-      bq[0] = lds_read_b128(brow + (((0 + hi) ^ bsw) << 4));
+      if (MODE == 0 && t == 8 && !more_in && vec_res) {   // top of the last unit
+        const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
+        const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[0][mt] = lds_read_b128(wslot + aoff[0] + mt * 4096);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            if (co_lane + mt * 32 + 8 * qd + 3 < p.Cout) {
+              if (r1) res4[mt][qd] = *reinterpret_cast<const f32x4*>(r1 + mt * 32 + 8 * qd);
+              if (r2) res4[mt][qd] += *reinterpret_cast<const f32x4*>(r2 + mt * 32 + 8 * qd);
+            }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) {
-          bq[(g + 1) & 1] = lds_read_b128(brow + (((2 * (g + 1) + hi) ^ bsw) << 4));
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[(g + 1) & 1][mt] = lds_read_b128(wslot + aoff[g + 1] + mt * 4096);
-        }
+        const int cur = g & 1, nxt = cur ^ 1;
+        bool fetched = true;
+        if (g < 3) load_ops(ibuf, t, g + 1, a_s[nxt], b_s[nxt]);
+        else if (t < 8) load_ops(ibuf, t + 1, 0, a_s[nxt], b_s[nxt]);
+        else if (more_in) load_ops(ibuf_next, 0, 0, a_s[nxt], b_s[nxt]);
+        else fetched = false;
+        if (fetched) wait_ops(std::integral_constant<int, NRD>(), a_s[cur], b_s[cur]);
+        else wait_ops(std::integral_constant<int, 0>(), a_s[cur], b_s[cur]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][e], bq[g & 1][e], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[cur][mt][e], b_s[cur][e], acc[mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (u + 1 < U) {
+        // W(u+2) was issued one unit ago and is the youngest DMA in flight -- except at t == 0 of chunks >= 1, where the
+        // halo tile of chunk c+1 was issued right after it (end of unit (c-1, 8)) and may keep flying
+        if (t == 0 && c >= 1 && more_in) wait_vmcnt<NIN_W>();
+        else wait_vmcnt<0>();
+        // bare s_barrier: __syncthreads() would add a fence = s_waitcnt vmcnt(0) and drain DMAs that may stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (u + 3 < U) issue_w(u + 3);
+        if (t == 8 && c + 2 < p.nchunks) issue_in(c + 2);
       }
     }
   }
 
   // ------------------------------------------------------------------------------------------------------------------
-  // epilogue.  acc[mt][r] = out channel cb*MW + mt*32 + 8*(r>>2) + 4*hi + (r&3) of pixel (y0 + wv, x0 + j)
+  // epilogue (bias is already inside acc)
   // ------------------------------------------------------------------------------------------------------------------
-  const int y = y0 + wv, x = x0 + j;
-  const bool pok = y < p.H && x < p.W;
-  float asum = 0.0f;
+  if constexpr (MODE == 3) {
+    // DCN offset/mask head: channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s:
+    // P_k[y][x] = s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid
+    float asum = 0.0f;
+    const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int co = cb * MW + mt * 32 + 8 * qd + 4 * hi;   // first of 4 consecutive output channels
-      if (co >= p.Cout) continue;
-      f32x4 v;
+      for (int qd = 0; qd < 4; ++qd) {
+        const int co = co_lane + mt * 32 + 8 * qd;
+        if (co >= p.Cout || !pok) continue;
+        f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (co + e < p.Cout) ? p.bias[co + e] : 0.0f;
-      }
-      if (p.out_mode == 3) {
-        if (!pok) continue;
-        const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
         if (co < p.n_off) {
-          // channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2, (co+2, co+3) of gt+1; pre-offset of tap k at scale s:
-          // P_k[y][x] = s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x)
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const int gt = (co >> 1) + h2, tap = gt % 9;
@@ -299,47 +368,89 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
           for (int e = 0; e < 4; ++e)
             if (co + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
         }
-        continue;
       }
-      if (p.act == 1) {
+    if (p.abs_sum) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-      } else if (p.act == 2) {
+      for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
+      if (l == 0) atomicAdd(p.abs_sum + ((blockIdx.x * 4 + wv + blockIdx.y * 31) & (C2M_ABS_SUM_SLOTS - 1)), (double)asum);
+    }
+    return;
+  }
+
+  // activation: ReLU = max(v, 0); LeakyReLU = max(v, slope * v) (0 <= slope <= 1, checked by the launcher)
+  if (p.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : v[e] * p.slope;
-      }
-      if (!pok) continue;
-      if (p.out_mode == 0) {
-        const size_t o = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co;
-        if (co + 3 < p.Cout && p.out_vec4) {
-          if (p.res1) { const f32x4 r1 = *reinterpret_cast<const f32x4*>(p.res1 + o); v += r1; }
-          if (p.res2) { const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + o); v += r2; }
-          *reinterpret_cast<f32x4*>(p.out + o) = v;
-        } else {
-          for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
-            float s = v[e];
-            if (p.res1) s += p.res1[o + e];
-            if (p.res2) s += p.res2[o + e];
-            p.out[o + e] = s;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], acc[mt][r] * p.slope);
+  }
+  if (!pok) return;
+
+  if constexpr (MODE == 0) {
+    float* ob = p.out + opix + co_lane;   // + mt*32 + 8*qd: immediate offsets
+    if (p.out_vec4) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int co = co_lane + mt * 32 + 8 * qd;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
+          if (co + 3 < p.Cout) {
+            v += res4[mt][qd];
+            *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+          } else {
+            for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+              float sv = v[e];
+              if (p.res1) sv += p.res1[opix + co + e];
+              if (p.res2) sv += p.res2[opix + co + e];
+              ob[mt * 32 + 8 * qd + e] = sv;
+            }
           }
         }
-      } else if (p.out_mode == 1) {
-        // PixelShuffle(2): channel 4*c2 + 2*dy + dx of pixel (y, x) -> channel c2 of pixel (2y + dy, 2x + dx)
-        const int c2 = co >> 2;
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          p.out[(size_t)b * p.out_img_pitch + (size_t)(2 * y + (e >> 1)) * p.out_row_pitch +
-                (size_t)(2 * x + (e & 1)) * p.out_pix_pitch + c2] = v[e];
-      } else {
-        const size_t HWs = (size_t)p.H * p.W;
-        for (int e = 0; e < 4 && co + e < p.Cout; ++e) p.out[((size_t)b * p.Cout + co + e) * HWs + (size_t)y * p.W + x] = v[e];
-      }
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
+          if (co_lane + cr < p.Cout) {
+            float sv = acc[mt][r];
+            if (p.res1) sv += p.res1[opix + co_lane + cr];
+            if (p.res2) sv += p.res2[opix + co_lane + cr];
+            ob[cr] = sv;
+          }
+        }
     }
-  }
-  if (p.out_mode == 3 && p.abs_sum) {
+  } else if constexpr (MODE == 1) {
+    // PixelShuffle(2): channel 4*c2 + 2*dy + dx of pixel (y, x) -> channel c2 of pixel (2y + dy, 2x + dx)
+    float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)(2 * y) * p.out_row_pitch + (size_t)(2 * x) * p.out_pix_pitch +
+                (co_lane >> 2);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
-    if (l == 0) atomicAdd(p.abs_sum + ((blockIdx.x * 4 + wv + blockIdx.y * 31) & (C2M_ABS_SUM_SLOTS - 1)), (double)asum);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        if (co_lane + mt * 32 + 8 * qd < p.Cout) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            ob[(size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 2 * qd] = acc[mt][4 * qd + e];
+        }
+  } else {
+    const size_t HWs = (size_t)p.H * p.W;
+    float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
+        if (co_lane + cr < p.Cout) ob[(size_t)cr * HWs] = acc[mt][r];
+      }
   }
 }
 
@@ -416,33 +527,41 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.res1 = d->res1; p.res2 = d->res2; p.mask_out = d->mask_out; p.flow = d->flow; p.fh = d->fh; p.fw = d->fw;
   p.scale = d->scale; p.n_off = d->n_off; p.abs_sum = d->abs_sum;
   p.out_vec4 = out_vec4 ? 1 : 0;
-  {
-    // anti-phase start-up delay: about half a workgroup's lifetime (nchunks * 9 units of ~8200 cycles when two workgroups
-    // share the matrix pipes), capped so that short launches do not pay more than they gain.  C2M_CONV_STAGGER overrides.
-    static const int env = [] { const char* e = getenv("C2M_CONV_STAGGER"); return e ? atoi(e) : -1; }();
-    const long long rounds = ((long long)p.tiles_x * p.tiles_y * p.B * ceil_div(d->Cout, conv_mw(d->Cout))) / 512;
-    int st_units = p.nchunks * 9 / 2;
-    if (rounds < 16) st_units = (int)(st_units * rounds / 32);
-    (void)st_units;
-    p.stagger = env >= 0 ? env : 0;
-  }
 
   const int MW = conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
+  if (d->act == C2M_ACT_LEAKY_RELU && !(d->slope >= 0.0f && d->slope <= 1.0f)) return C2M_ERR_UNSUPPORTED;   // max(v, slope*v)
+  for (int sidx = 0; sidx < d->nsrc; ++sidx) {   // 32-bit byte offsets inside one sample (buffer addressing)
+    const long long ext = ((long long)(d->H - 1) * d->src[sidx].row_pitch + (long long)(d->W - 1) * d->src[sidx].pix_pitch +
+                           d->src[sidx].C) * 4;
+    if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
+  }
   dim3 grid((unsigned)ntile, ceil_div(d->Cout, MW));
   hipStream_t st = as_stream(stream);
   ProfileScope prof(C2M_KERNEL_CONV3X3, st);
+  const size_t ldsb = 2 * conv::IN_BYTES + 3 * (size_t)MW * 128 + 1024;
+  int rc = C2M_OK;
+  auto go = [&](auto kern, unsigned long long& done) {
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsb, done)) != C2M_OK) return;
+    hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
+  };
+  static unsigned long long done[2][4] = {};
   if (MW == 64) {
-    const size_t ldsb = 2 * conv::IN_BYTES + 3 * 64 * 128 + 1024;
-    static unsigned long long lds_set = 0;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_kernel<2>), ldsb, lds_set)) return rc;
-    hipLaunchKernelGGL(conv::conv3x3_kernel<2>, grid, dim3(256), ldsb, st, p);
+    switch (d->out_mode) {
+      case 0: go(&conv::conv3x3_kernel<2, 0>, done[1][0]); break;
+      case 1: go(&conv::conv3x3_kernel<2, 1>, done[1][1]); break;
+      case 2: go(&conv::conv3x3_kernel<2, 2>, done[1][2]); break;
+      default: go(&conv::conv3x3_kernel<2, 3>, done[1][3]); break;
+    }
   } else {
-    const size_t ldsb = 2 * conv::IN_BYTES + 3 * 32 * 128 + 1024;
-    static unsigned long long lds_set = 0;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_kernel<1>), ldsb, lds_set)) return rc;
-    hipLaunchKernelGGL(conv::conv3x3_kernel<1>, grid, dim3(256), ldsb, st, p);
+    switch (d->out_mode) {
+      case 0: go(&conv::conv3x3_kernel<1, 0>, done[0][0]); break;
+      case 1: go(&conv::conv3x3_kernel<1, 1>, done[0][1]); break;
+      case 2: go(&conv::conv3x3_kernel<1, 2>, done[0][2]); break;
+      default: go(&conv::conv3x3_kernel<1, 3>, done[0][3]); break;
+    }
   }
+  if (rc != C2M_OK) return rc;
   return check_launch();
 }
