@@ -333,7 +333,13 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
 class BorderedNHWC:
     """Zero-bordered channels-last copy [B][H+3][W+3][C] of an NCHW feature map (what the DCNv2 kernels gather from)."""
 
+    def __new__(cls, x=None):
+        pre = bordered_of(x) if x is not None else None   # already the interior view of a bordered buffer: no copy
+        return pre if pre is not None else super().__new__(cls)
+
     def __init__(self, x):
+        if bordered_of(x) is self:
+            return
         x = _dev_f32(x, "x")
         self.B, self.C, self.H, self.W = x.shape
         self.buf = torch.empty((self.B, self.H + 3, self.W + 3, self.C), dtype=torch.float32, device=x.device)
@@ -394,4 +400,76 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
                                                          offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1, 1,
                                                          1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope)),
                    "c2m_dcn_v2_forward_nhwc_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VGG-style feature stacks (conv3x3 + ReLU + 2x2 max-pool) on the channels-last kernels
+# ---------------------------------------------------------------------------------------------------------------------
+def _bordered_empty(B, C, H, W, device):
+    """BorderedNHWC whose border is zero and whose interior is uninitialised (to be written by a conv epilogue)."""
+    o = BorderedNHWC.__new__(BorderedNHWC)
+    o.B, o.C, o.H, o.W = B, C, H, W
+    o.buf = torch.empty((B, H + 3, W + 3, C), dtype=torch.float32, device=device)
+    o.buf[:, 0].zero_()
+    o.buf[:, H + 1:].zero_()
+    o.buf[:, 1:H + 1, 0].zero_()
+    o.buf[:, 1:H + 1, W + 1:].zero_()
+    return o
+
+
+def bordered_of(t):
+    """The BorderedNHWC a tensor is the interior view of (set by vgg_stack_forward), else None."""
+    return getattr(t, "_c2m_bordered", None)
+
+
+def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False):
+    """Run an ordered {name: nn.Conv2d(3x3, pad 1) | nn.ReLU | nn.MaxPool2d(2, 2)} stack (torchvision's vgg `features`
+    layout, mmsr/models/archs/vgg_arch.py:107-123) on the fused channels-last convolution: every conv + its ReLU is one
+    launch.  x: [B,3,H,W] image; (x - mean) / std is applied while the image is widened to the kernel's 32-channel chunk.
+    Returns {tap name: tensor}; tapped activations are written by the conv epilogue straight into zero-bordered
+    channels-last buffers (logical NCHW views of their interiors are returned: the DCNv2 gathers and the offset
+    convolutions of the decoder read those buffers in place).  last_nchw: the final layer's output as a contiguous NCHW
+    tensor under the key of that layer (the correlation kernels read planar features)."""
+    names = list(layers.keys())
+    B, C, H, W = x.shape
+    dev = x.device
+    cur = torch.zeros((B, 32, H, W), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+    xin = x.float()
+    if mean is not None:
+        xin = (xin - mean) / std
+    cur[:, :C] = xin
+    out, k = {}, 0
+    while k < len(names):
+        name, layer = names[k], layers[names[k]]
+        if isinstance(layer, torch.nn.Conv2d):
+            if layer.kernel_size != (3, 3) or layer.stride != (1, 1) or layer.padding != (1, 1) or layer.groups != 1:
+                raise _lib.C2MError(f"vgg_stack_forward: {name} is not a 3x3 / stride 1 / pad 1 convolution")
+            relu = k + 1 < len(names) and isinstance(layers[names[k + 1]], torch.nn.ReLU)
+            tap_name = names[k + 1] if (relu and names[k + 1] in taps) else (name if name in taps and not relu else None)
+            if name in taps and relu:
+                raise _lib.C2MError("tapping a conv output that is followed by an in-place ReLU is not supported")
+            last = (k + (2 if relu else 1)) >= len(names)
+            Bc, _, Hc, Wc = cur.shape
+            if last and last_nchw:
+                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out_mode="nchw")
+                out[names[k + 1] if relu else name] = cur
+            elif tap_name is not None:
+                bo = _bordered_empty(Bc, layer.out_channels, Hc, Wc, dev)
+                view = bo.interior()
+                conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out=view)
+                view._c2m_bordered = bo
+                out[tap_name] = view
+                cur = view
+            else:
+                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE)
+            k += 2 if relu else 1
+        elif isinstance(layer, torch.nn.MaxPool2d):
+            cur = torch.nn.functional.max_pool2d(cur, layer.kernel_size, layer.stride, layer.padding)
+            k += 1
+        elif isinstance(layer, torch.nn.ReLU):
+            cur = torch.relu(cur)
+            k += 1
+        else:
+            raise _lib.C2MError(f"vgg_stack_forward: unsupported layer {name}: {type(layer).__name__}")
     return out

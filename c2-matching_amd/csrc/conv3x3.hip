@@ -78,6 +78,7 @@ struct Params {
   int fh, fw, scale, n_off;   // n_off = 2*dg*9 offset channels (the rest are mask logits)
   double* abs_sum;       // mode 3: C2M_ABS_SUM_SLOTS partial sums of |raw offset| or nullptr
   int out_vec4;          // mode 0: out / res pitches and bases are 16-byte aligned -> float4 stores
+  int tpw;               // consecutive tiles per workgroup (>= 1)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -125,24 +126,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 constexpr unsigned kOOB = 0x80000000u;   // voffset of a lane that must read zeros (>= any num_records used here)
 
 // MODE = Params::out_mode (compile time: each store flavour is its own kernel, the others' code is not even loaded)
+//
+// A workgroup processes p.tpw consecutive tiles as ONE continuous stream of chunks and units: the halo tile of the next
+// tile's first chunks and its weight images are DMA'd while the current tile is still being multiplied, so only the first
+// tile of a workgroup waits for memory; bias, descriptors and operand addresses are set up once.
 template <int MT, int MODE>
 __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   constexpr int MW = 32 * MT;
   constexpr int WSLOT = MW * 128;          // bytes of one unit's weight image
   constexpr int NW_W = MT;                 // weight DMA instructions per wave and unit (1 KiB each)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  // [in0 | in1 | w ring x3 | dummy 1 KiB]
+  // [in0 | in1 | w ring x3 | dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address
   const unsigned in_base = lds0, w_base = lds0 + 2 * IN_BYTES, dummy = w_base + 3 * WSLOT;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntile = p.tiles_x * p.tiles_y * p.B;
-  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tile_first = xcd_remap(blockIdx.x, gridDim.x) * p.tpw;
+  const int ntl = min(p.tpw, ntile - tile_first);   // >= 1 by construction of the grid
   const int cb = blockIdx.y;
-  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
-  const int x0 = tx * TW, y0 = ty * TH;
   const int U = p.nchunks * 9;
+  const int G = ntl * p.nchunks;                     // chunks of this workgroup; units: 9 * G
 
   // ------------------------------------------------------------------------------------------------------------------
   // DMA plumbing.  Every operand byte travels global -> LDS by buffer_load_dwordx4 ... lds (1 KiB per wave-instruction:
@@ -152,42 +157,57 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   //   halo    : instruction n (64 pieces of 16 B) is issued by wave n & 3 as its slot n >> 2; piece P = 64n + lane is pixel
   //             pl = P >> 3 of the 34 x 6 tile, LDS slot P & 7, logical piece q = slot ^ ((pl >> 1) & 7) (channels 4q..4q+3
   //             of the chunk).  voffset = byte offset of (pixel, 4q) inside the sample, or kOOB outside the image / tile;
-  //             soffset = the chunk's channel offset.  The 7 voffsets are computed once per source tensor.
+  //             soffset = the chunk's channel offset.  The 7 voffsets are computed once per (tile, source tensor).
   // ------------------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * U * (MW * 32), (unsigned)U * WSLOT);
   const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
-  auto issue_w = [&](int u) __attribute__((always_inline)) {
-    const unsigned dst = w_base + (u % 3) * WSLOT + wv * NW_W * 1024;
+  auto issue_w = [&](int gu) __attribute__((always_inline)) {   // gu: unit index in the workgroup's stream
+    const int u = gu % U;
+    const unsigned dst = w_base + (gu % 3) * WSLOT + wv * NW_W * 1024;   // U % 3 == 0: gu % 3 == u % 3
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 0, 0);
     if constexpr (NW_W == 2)   // the instruction offset advances BOTH the global and the LDS address
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 1024, 0);
   };
 
+  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+    b = tile / (p.tiles_x * p.tiles_y);
+    x0 = tx * TW;
+    y0 = ty * TH;
+  };
+  // state of the DMA side (it runs up to two chunks -- possibly one tile -- ahead of the MFMA side)
   unsigned ivoff[NIN_W];
+  int ib = 0, iy0 = 0, ix0 = 0;
+  __amdgpu_buffer_rsrc_t rs0, rs1;
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
     int ry = 0, rx = 8 * wv + (l >> 3);   // pixel of slot 0 (< 34: row 0 of the halo tile); each further slot is 32 pixels on
 #pragma unroll
     for (int sl = 0; sl < NIN_W; ++sl) {
       const int n = wv + 4 * sl;
       const int q = (l & 7) ^ ((4 * n + (l >> 4)) & 7);
-      const int iy = y0 - 1 + ry, ix = x0 - 1 + rx;
+      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
       const bool ok = n < NIN_REAL && ry < HH_ && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * q) * 4u : kOOB;
       rx += 32;
       if (rx >= HW_) { rx -= HW_; ry += 1; }
     }
   };
-  auto src_rsrc = [&](const Src& S) __attribute__((always_inline)) {
+  auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
     const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
     return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
   };
-  const __amdgpu_buffer_rsrc_t rs0 = src_rsrc(p.src[0]), rs1 = src_rsrc(p.src[1]);
-  auto issue_in = [&](int c) __attribute__((always_inline)) {
-    const int c0 = c * KCH;
+  auto issue_in = [&](int gc) __attribute__((always_inline)) {   // gc: chunk index in the workgroup's stream
+    const int it = gc / p.nchunks, c0 = (gc - it * p.nchunks) * KCH;
     const bool first = c0 < p.src[0].C;
-    if (c0 == 0) set_source(p.src[0]);
-    else if (c0 == p.src[0].C) set_source(p.src[1]);
-    const unsigned buf = in_base + (c & 1) * IN_BYTES;
+    if (c0 == 0) {
+      tile_coords(tile_first + it, ib, iy0, ix0);
+      rs0 = src_rsrc(p.src[0], ib);
+      rs1 = src_rsrc(p.src[1], ib);
+      set_source(p.src[0]);
+    } else if (c0 == p.src[0].C) {
+      set_source(p.src[1]);
+    }
+    const unsigned buf = in_base + (gc & 1) * IN_BYTES;
     const int soff = (first ? c0 : c0 - p.src[0].C) * 4;
 #pragma unroll
     for (int sl = 0; sl < NIN_W; ++sl) {
@@ -198,34 +218,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     }
   };
 
+  // acc[mt][r] = out channel cb*MW + mt*32 + 8*(r>>2) + 4*hi + (r&3) of pixel (y, x).  The bias of this cout block is parked
+  // in LDS (published by the first barrier) and added in the epilogue: holding it in registers across tiles costs 16*MT VGPRs
   // ------------------------------------------------------------------------------------------------------------------
-  // accumulators start from the bias.  acc[mt][r] = out channel cb*MW + mt*32 + 8*(r>>2) + 4*hi + (r&3) of pixel (y, x)
-  // ------------------------------------------------------------------------------------------------------------------
-  const int y = y0 + wv, x = x0 + j;
-  const bool pok = y < p.H && x < p.W;
   const int co_lane = cb * MW + 4 * hi;    // + mt*32 + 8*qd + e
+  const unsigned bias_lds = dummy + 1024;  // MW floats
+  if (tid < MW) {
+    const int co = cb * MW + tid;
+    *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+  }
   f32x16 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int co = co_lane + mt * 32 + 8 * qd;
-      f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (p.bias) {
-        if (co + 3 < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-        else
-          for (int e = 0; e < 4; ++e) bv[e] = co + e < p.Cout ? p.bias[co + e] : 0.0f;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[mt][4 * qd + e] = bv[e];
-    }
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-  // A-operand byte addresses: ring slot sl, k-quad g (row = cout j of tile mt, piece 2g + hi), + mt * 4096.  Loop invariant.
-  unsigned aaddr[3][4];
+  // A-operand byte addresses of ring slot 0: k-quad g (row = cout j of tile mt, piece 2g + hi); + slot * WSLOT + mt * 4096 go
+  // into the instruction's offset field.  Loop invariant.
+  unsigned aaddr[4];
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) aaddr[sl][g] = w_base + sl * WSLOT + j * 128 + (((2 * g + hi) ^ ((j >> 1) & 7)) << 4);
+  for (int g = 0; g < 4; ++g) aaddr[g] = w_base + j * 128 + (((2 * g + hi) ^ ((j >> 1) & 7)) << 4);
 
   // Operand reads are inline asm with hand-placed s_waitcnt: hipcc's own counter tracking collapses to lgkmcnt(0) after
   // every other k-quad here, which waits for the reads just issued for the NEXT quad (one exposed LDS latency per 8 MFMAs).
@@ -238,8 +250,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     const int pl = (wv + dy) * HW_ + j + dx;
     const unsigned baddr = ibuf + pl * 128 + ((((2 * g + hi) ^ (pl >> 1)) & 7) << 4);
     asm volatile("ds_read_b128 %0, %1" : "=v"(bq) : "v"(baddr) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aaddr[t % 3][g]) : "memory");   // 9 % 3 == 0: tap t always sits in ring slot t % 3
-    if constexpr (MT == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aaddr[t % 3][g]) : "memory");
+    // 9 % 3 == 0: tap t always sits in ring slot t % 3 (t is a constant after unrolling: the switch folds)
+    if constexpr (MT == 2) {
+      switch (t % 3) {
+        case 0:
+          asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aaddr[g]) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(aaddr[g]) : "memory");
+          break;
+        case 1:
+          asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[0]) : "v"(aaddr[g]) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(a[1]) : "v"(aaddr[g]) : "memory");
+          break;
+        default:
+          asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(a[0]) : "v"(aaddr[g]) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(a[1]) : "v"(aaddr[g]) : "memory");
+          break;
+      }
+    } else {
+      switch (t % 3) {
+        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(aaddr[g]) : "memory"); break;
+        case 1: asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[0]) : "v"(aaddr[g]) : "memory"); break;
+        default: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(a[0]) : "v"(aaddr[g]) : "memory"); break;
+      }
+    }
   };
   // wait until at most N LDS reads are in flight; the operands are tied to the statement so that no MFMA reading them can be
   // scheduled above it
@@ -249,24 +282,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq), "+v"(a[0]) : "n"(N));
   };
 
-  // residuals (NHWC mode) are fetched at the top of the last unit: their latency runs under MFMAs, not in front of the stores
-  const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
-  f32x4 res4[MT][4];
-  const bool vec_res = MODE == 0 && p.out_vec4 && pok && (p.res1 || p.res2);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) res4[mt][qd] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
   // ------------------------------------------------------------------------------------------------------------------
-  // main loop.  Unit u = (chunk c, tap t).  Invariant at the top of unit u: the weight images of units u and u+1 and the
-  // halo tile of chunk c (and, from (c, 2) on, of chunk c+1) are visible to every wave; W(u+2) is in flight.  The barrier
-  // at the END of unit u publishes W(u+2) and frees ring slot u % 3 for W(u+3).  Because unit u+1's operands are visible
-  // one unit early, the last k-quad of unit u already fetches the first operands of unit u+1: MFMAs issue back to back
-  // across the barrier.
+  // main loop over the workgroup's chunk stream.  Unit gu = (chunk gc, tap t).  Invariant at the top of unit gu: the weight
+  // images of units gu and gu+1 and the halo tile of chunk gc (and, from (gc, 2) on, of chunk gc+1) are visible to every
+  // wave; W(gu+2) is in flight.  The barrier at the END of unit gu publishes W(gu+2) and frees ring slot gu % 3 for W(gu+3).
+  // Because unit gu+1's operands are visible one unit early, the last k-quad of unit gu already fetches the first operands
+  // of unit gu+1: MFMAs issue back to back across the barrier -- and across tiles.
   // ------------------------------------------------------------------------------------------------------------------
   issue_in(0);
-  if (p.nchunks > 1) issue_in(1);
+  if (G > 1) issue_in(1);
   issue_w(0);
   issue_w(1);
   issue_w(2);
@@ -276,23 +300,39 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   // two operand sets, used alternately (k-quad g of any unit reads set g & 1: 4 quads per unit keeps the parity fixed)
   f32x4 a_s[2][MT], b_s[2];
   load_ops(in_base, 0, 0, a_s[0], b_s[0]);
-  for (int c = 0; c < p.nchunks; ++c) {
-    const unsigned ibuf = in_base + (c & 1) * IN_BYTES, ibuf_next = in_base + ((c + 1) & 1) * IN_BYTES;
-    const bool more_in = c + 1 < p.nchunks;
+  f32x4 res4[MT][4];
+  for (int gc = 0; gc < G; ++gc) {
+    const unsigned ibuf = in_base + (gc & 1) * IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * IN_BYTES;
+    const bool more_in = gc + 1 < G;
+    const int it = gc / p.nchunks;
+    const bool last_chunk = gc - it * p.nchunks == p.nchunks - 1;   // of its tile
+    // MFMA-side tile (epilogue addresses)
+    int b, y0, x0;
+    tile_coords(tile_first + it, b, y0, x0);
+    const int y = y0 + wv, x = x0 + j;
+    const bool pok = y < p.H && x < p.W;
+    const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
+    const bool vec_res = MODE == 0 && p.out_vec4 && pok && (p.res1 || p.res2);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int u = c * 9 + t;
-      if (MODE == 0 && t == 8 && !more_in && vec_res) {   // top of the last unit
-        const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
-        const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
+      const int gu = gc * 9 + t;
+      if (MODE == 0 && t == 8 && last_chunk) {   // top of the tile's last unit: residuals -- their latency runs under MFMAs
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
-            if (co_lane + mt * 32 + 8 * qd + 3 < p.Cout) {
-              if (r1) res4[mt][qd] = *reinterpret_cast<const f32x4*>(r1 + mt * 32 + 8 * qd);
-              if (r2) res4[mt][qd] += *reinterpret_cast<const f32x4*>(r2 + mt * 32 + 8 * qd);
-            }
+          for (int qd = 0; qd < 4; ++qd) res4[mt][qd] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (vec_res) {
+          const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
+          const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              if (co_lane + mt * 32 + 8 * qd + 3 < p.Cout) {
+                if (r1) res4[mt][qd] = *reinterpret_cast<const f32x4*>(r1 + mt * 32 + 8 * qd);
+                if (r2) res4[mt][qd] += *reinterpret_cast<const f32x4*>(r2 + mt * 32 + 8 * qd);
+              }
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -311,146 +351,160 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[cur][mt][e], b_s[cur][e], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (u + 1 < U) {
-        // W(u+2) was issued one unit ago and is the youngest DMA in flight -- except at t == 0 of chunks >= 1, where the
-        // halo tile of chunk c+1 was issued right after it (end of unit (c-1, 8)) and may keep flying
-        if (t == 0 && c >= 1 && more_in) wait_vmcnt<NIN_W>();
+      if (gu + 1 < 9 * G) {
+        // W(gu+2) was issued one unit ago and is the youngest DMA in flight -- except at t == 0 of chunks >= 1, where the
+        // halo tile of chunk gc+1 was issued right after it (end of unit (gc-1, 8)) and may keep flying
+        if (t == 0 && gc >= 1 && more_in) wait_vmcnt<NIN_W>();
         else wait_vmcnt<0>();
         // bare s_barrier: __syncthreads() would add a fence = s_waitcnt vmcnt(0) and drain DMAs that may stay in flight
         __builtin_amdgcn_s_barrier();
-        if (u + 3 < U) issue_w(u + 3);
-        if (t == 8 && c + 2 < p.nchunks) issue_in(c + 2);
+        if (gu + 3 < 9 * G) issue_w(gu + 3);
+        if (t == 8 && gc + 2 < G) issue_in(gc + 2);
       }
     }
-  }
-
-  // ------------------------------------------------------------------------------------------------------------------
-  // epilogue (bias is already inside acc)
-  // ------------------------------------------------------------------------------------------------------------------
-  if constexpr (MODE == 3) {
-    // DCN offset/mask head: channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s:
-    // P_k[y][x] = s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid
-    float asum = 0.0f;
-    const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
+    if (!last_chunk) continue;
+    {   // + bias (LDS, one b128 per 4 consecutive channels)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int co = co_lane + mt * 32 + 8 * qd;
-        if (co >= p.Cout || !pok) continue;
-        f32x4 v;
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (mt * 32 + 8 * qd + 4 * hi) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
-        if (co < p.n_off) {
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int gt = (co >> 1) + h2, tap = gt % 9;
-            const int ki = tap / 3, kj = tap - 3 * ki;
-            float fy = 0.0f, fx = 0.0f;
-            if (p.flow) {
-              const int ys = y - p.scale * ki, xs = x - p.scale * kj;
-              if (ys >= 0 && xs >= 0) {
-                const int yy = ys / p.scale, xx = xs / p.scale;
-                if (yy < p.fh && xx < p.fw) {
-                  const float2 f = reinterpret_cast<const float2*>(p.flow)[((size_t)b * p.fh + yy) * p.fw + xx];
-                  fx = f.x * (float)p.scale;
-                  fy = f.y * (float)p.scale;
-                }
-              }
-            }
-            asum += fabsf(v[2 * h2]) + fabsf(v[2 * h2 + 1]);
-            p.out[((size_t)b * p.n_off + co + 2 * h2) * HWs + pix] = v[2 * h2] + fy;
-            p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
-          }
-        } else {
-          const int nm = p.Cout - p.n_off;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
+          for (int e = 0; e < 4; ++e) acc[mt][4 * qd + e] += bv[e];
         }
-      }
-    if (p.abs_sum) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
-      if (l == 0) atomicAdd(p.abs_sum + ((blockIdx.x * 4 + wv + blockIdx.y * 31) & (C2M_ABS_SUM_SLOTS - 1)), (double)asum);
     }
-    return;
-  }
 
-  // activation: ReLU = max(v, 0); LeakyReLU = max(v, slope * v) (0 <= slope <= 1, checked by the launcher)
-  if (p.act == 1) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
-  } else if (p.act == 2) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], acc[mt][r] * p.slope);
-  }
-  if (!pok) return;
-
-  if constexpr (MODE == 0) {
-    float* ob = p.out + opix + co_lane;   // + mt*32 + 8*qd: immediate offsets
-    if (p.out_vec4) {
+    // ----------------------------------------------------------------------------------------------------------------
+    // epilogue of the tile (bias is already inside acc); the accumulators restart from the bias for the next tile
+    // ----------------------------------------------------------------------------------------------------------------
+    if constexpr (MODE == 3) {
+      // DCN offset/mask head: channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s:
+      // P_k[y][x] = s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid
+      float asum = 0.0f;
+      const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const int co = co_lane + mt * 32 + 8 * qd;
+          if (co >= p.Cout || !pok) continue;
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
-          if (co + 3 < p.Cout) {
-            v += res4[mt][qd];
-            *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
-          } else {
-            for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
-              float sv = v[e];
-              if (p.res1) sv += p.res1[opix + co + e];
-              if (p.res2) sv += p.res2[opix + co + e];
-              ob[mt * 32 + 8 * qd + e] = sv;
+          if (co < p.n_off) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const int gt = (co >> 1) + h2, tap = gt % 9;
+              const int ki = tap / 3, kj = tap - 3 * ki;
+              float fy = 0.0f, fx = 0.0f;
+              if (p.flow) {
+                const int ys = y - p.scale * ki, xs = x - p.scale * kj;
+                if (ys >= 0 && xs >= 0) {
+                  const int yy = ys / p.scale, xx = xs / p.scale;
+                  if (yy < p.fh && xx < p.fw) {
+                    const float2 f = reinterpret_cast<const float2*>(p.flow)[((size_t)b * p.fh + yy) * p.fw + xx];
+                    fx = f.x * (float)p.scale;
+                    fy = f.y * (float)p.scale;
+                  }
+                }
+              }
+              asum += fabsf(v[2 * h2]) + fabsf(v[2 * h2 + 1]);
+              p.out[((size_t)b * p.n_off + co + 2 * h2) * HWs + pix] = v[2 * h2] + fy;
+              p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
             }
+          } else {
+            const int nm = p.Cout - p.n_off;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (co + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
           }
         }
-    } else {
+      if (p.abs_sum) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
-          if (co_lane + cr < p.Cout) {
-            float sv = acc[mt][r];
-            if (p.res1) sv += p.res1[opix + co_lane + cr];
-            if (p.res2) sv += p.res2[opix + co_lane + cr];
-            ob[cr] = sv;
-          }
-        }
-    }
-  } else if constexpr (MODE == 1) {
-    // PixelShuffle(2): channel 4*c2 + 2*dy + dx of pixel (y, x) -> channel c2 of pixel (2y + dy, 2x + dx)
-    float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)(2 * y) * p.out_row_pitch + (size_t)(2 * x) * p.out_pix_pitch +
-                (co_lane >> 2);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd)
-        if (co_lane + mt * 32 + 8 * qd < p.Cout) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            ob[(size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 2 * qd] = acc[mt][4 * qd + e];
-        }
-  } else {
-    const size_t HWs = (size_t)p.H * p.W;
-    float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
-        if (co_lane + cr < p.Cout) ob[(size_t)cr * HWs] = acc[mt][r];
+        for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
+        if (l == 0) atomicAdd(p.abs_sum + ((blockIdx.x * 4 + wv + blockIdx.y * 31 + it) & (C2M_ABS_SUM_SLOTS - 1)), (double)asum);
       }
+    } else {
+      // activation: ReLU = max(v, 0); LeakyReLU = max(v, slope * v) (0 <= slope <= 1, checked by the launcher)
+      if (p.act == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], 0.0f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = fmaxf(acc[mt][r], acc[mt][r] * p.slope);
+      }
+      if (pok) {
+        if constexpr (MODE == 0) {
+          float* ob = p.out + opix + co_lane;   // + mt*32 + 8*qd: immediate offsets
+          if (p.out_vec4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                const int co = co_lane + mt * 32 + 8 * qd;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
+                if (co + 3 < p.Cout) {
+                  v += res4[mt][qd];
+                  *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+                } else {
+                  for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
+                    float sv = v[e];
+                    if (p.res1) sv += p.res1[opix + co + e];
+                    if (p.res2) sv += p.res2[opix + co + e];
+                    ob[mt * 32 + 8 * qd + e] = sv;
+                  }
+                }
+              }
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
+                if (co_lane + cr < p.Cout) {
+                  float sv = acc[mt][r];
+                  if (p.res1) sv += p.res1[opix + co_lane + cr];
+                  if (p.res2) sv += p.res2[opix + co_lane + cr];
+                  ob[cr] = sv;
+                }
+              }
+          }
+        } else if constexpr (MODE == 1) {
+          // PixelShuffle(2): channel 4*c2 + 2*dy + dx of pixel (y, x) -> channel c2 of pixel (2y + dy, 2x + dx)
+          float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)(2 * y) * p.out_row_pitch +
+                      (size_t)(2 * x) * p.out_pix_pitch + (co_lane >> 2);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+              if (co_lane + mt * 32 + 8 * qd < p.Cout) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  ob[(size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 2 * qd] = acc[mt][4 * qd + e];
+              }
+        } else {
+          const size_t HWs = (size_t)p.H * p.W;
+          float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
+              if (co_lane + cr < p.Cout) ob[(size_t)cr * HWs] = acc[mt][r];
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
   }
 }
 
@@ -537,10 +591,17 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
                            d->src[sidx].C) * 4;
     if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
   }
-  dim3 grid((unsigned)ntile, ceil_div(d->Cout, MW));
+  // tiles per workgroup: as many as keep >= 8 full rounds of 512 resident workgroups (2 per CU) -- long streams amortise the
+  // set-up and the first DMA wait, short launches stay balanced.  C2M_CONV_TPW overrides (experiments).
+  static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
+  const int ncb = ceil_div(d->Cout, MW);
+  long long tpw = env_tpw > 0 ? env_tpw : (ntile * ncb) / (8 * 512);
+  tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+  p.tpw = (int)tpw;
+  dim3 grid((unsigned)((ntile + tpw - 1) / tpw), ncb);
   hipStream_t st = as_stream(stream);
   ProfileScope prof(C2M_KERNEL_CONV3X3, st);
-  const size_t ldsb = 2 * conv::IN_BYTES + 3 * (size_t)MW * 128 + 1024;
+  const size_t ldsb = 2 * conv::IN_BYTES + 3 * (size_t)MW * 128 + 1024 + 256;   // halo x2, weight ring, DMA dummy, bias
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& done) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsb, done)) != C2M_OK) return;

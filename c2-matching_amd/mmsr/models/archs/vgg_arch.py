@@ -111,7 +111,28 @@ class VGGFeatureExtractor(nn.Module):
             self.register_buffer('mean', torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
             self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
+    def _use_fused(self, x):
+        """Inference on the gfx950 channels-last kernels: no autograd, fp32 image on the GPU, the plain torchvision stack
+        (3x3 / stride 1 / pad 1 convolutions, ReLUs, 2x2 max-pools) and post-ReLU taps only."""
+        def ok(m):
+            if isinstance(m, nn.Conv2d):
+                return (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1 and
+                        (m.in_channels == 3 or m.in_channels % 32 == 0))
+            if isinstance(m, nn.MaxPool2d):
+                return m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2))
+            return isinstance(m, nn.ReLU)
+        return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and
+                not torch.is_autocast_enabled('cuda') and all(ok(m) for m in self.vgg_net._modules.values()) and
+                all(n.startswith('relu') for n in self.layer_name_list))
+
     def forward(self, x):
+        if self._use_fused(x):
+            # inference on the gfx950 channels-last kernels: conv + ReLU in one launch, tapped activations written straight
+            # into the zero-bordered channels-last buffers the DCNv2 warps gather from (no clone, no layout copy)
+            from c2m_amd import ops as _ops
+            return _ops.vgg_stack_forward(self.vgg_net._modules, x, taps=self.layer_name_list,
+                                          mean=self.mean if self.use_input_norm else None,
+                                          std=self.std if self.use_input_norm else None)
         if self.use_input_norm:
             x = (x - self.mean) / self.std
         taps = {}

@@ -137,3 +137,44 @@ def test_dcn_head_matches_oracle_assembly(ops, dev):
         assert abs(float(abs_sum.sum()) - want_abs) < 1e-4 * want_abs
     off0, _ = ops.conv3x3_dcn_head(feat, wt, bs, dg, None, 4)
     assert float((off0.double() - torch.cat((o1, o2), 1)).abs().max()) < tol
+
+
+def test_vgg_and_extractor_stacks_match_stock_torch(dev):
+    """VGGFeatureExtractor / ContrasExtractorSep run their conv+ReLU stacks on the fused channels-last kernel under no_grad;
+    with gradients enabled they run module by module on stock torch.  Same weights, same image: the taps agree to fp32
+    rounding; tapped activations are interior views of zero-bordered channels-last buffers."""
+    import warnings
+    import c2m_amd
+    from mmsr.models.archs.contras_extractor_arch import ContrasExtractorSep
+    from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        vgg = VGGFeatureExtractor(["relu1_1", "relu2_1", "relu3_1"], "vgg19").to(dev).eval()
+        ext = ContrasExtractorSep().to(dev).eval()
+    torch.manual_seed(3)
+    for m in list(vgg.modules()) + list(ext.modules()):
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    img = torch.rand(2, 3, 72, 88, device=dev)
+    img2 = torch.rand(2, 3, 72, 88, device=dev)
+    with torch.enable_grad():
+        want = vgg(img)
+        want_e = ext(img, img2)
+    with torch.no_grad():
+        assert vgg._use_fused(img)
+        got = vgg(img)
+        got_e = ext(img, img2)
+    for k in ("relu1_1", "relu2_1", "relu3_1"):
+        assert got[k].shape == want[k].shape
+        err = float((got[k] - want[k]).abs().max())
+        assert err < 2e-4 * max(1.0, float(want[k].abs().max())), (k, err)   # stock path may use Winograd convolutions
+        bo = c2m_amd.ops.bordered_of(got[k])
+        assert bo is not None and c2m_amd.ops.BorderedNHWC(got[k]) is bo
+        H, W = got[k].shape[2:]
+        assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, H + 1:].abs().max()) == 0
+        assert float(bo.buf[:, :, 0].abs().max()) == 0 and float(bo.buf[:, :, W + 1:].abs().max()) == 0
+    for k in ("dense_features1", "dense_features2"):
+        assert got_e[k].is_contiguous() and got_e[k].shape == want_e[k].shape
+        err = float((got_e[k] - want_e[k].detach()).abs().max())
+        assert err < 2e-4 * max(1.0, float(want_e[k].abs().max())), (k, err)
