@@ -28,7 +28,7 @@ class Conv3x3Desc(ctypes.Structure):
                 ("wr", _vp), ("bias", _vp), ("act", _i), ("slope", ctypes.c_float), ("out_mode", _i), ("out", _vp),
                 ("out_pix_pitch", _i), ("out_row_pitch", _i), ("out_img_pitch", ctypes.c_longlong), ("res1", _vp),
                 ("res2", _vp), ("mask_out", _vp), ("flow", _vp), ("fh", _i), ("fw", _i), ("scale", _i), ("n_off", _i),
-                ("abs_sum", _vp)]
+                ("abs_sum", _vp), ("cout_offset", _i), ("cout_total", _i)]
 
 
 class C2MError(RuntimeError):

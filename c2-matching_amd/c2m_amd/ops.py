@@ -182,12 +182,15 @@ class _WeightCache:
     def __init__(self):
         self._d = {}
 
-    def get(self, weight, pad_cin_to=None):
+    def get(self, weight, pad_cin_to=None, rows=None):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
-        hit = self._d.get(id(weight))
+        slot = (id(weight), rows)
+        hit = self._d.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
         w = weight.detach()
+        if rows is not None:
+            w = w[rows[0]:rows[1]]
         if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
             raise _lib.C2MError("conv3x3: weight must be a float32 GPU tensor [Cout, Cin, 3, 3]")
         Co, Ci = w.shape[:2]
@@ -202,7 +205,7 @@ class _WeightCache:
         wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(L.c2m_conv3x3_relayout_f32(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout_f32")
-        self._d[id(weight)] = (key, wr)
+        self._d[slot] = (key, wr)
         return wr
 
 
@@ -290,7 +293,9 @@ def index_to_flow(max_idx):
 def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, abs_sum=None):
     """The DCN offset/mask head (conv_offset_mask of DCN_sep_pre_multi_offset, dcn_v2.py:229-245) fused with the
     pre-offset construction: -> (offset [B,2*dg*9,H,W], mask [B,dg*9,H,W]) planar, ready for dcn_v2_forward.
-    flow: index_to_flow(max_idx) of the matched LR features (or None: no pre-offset); scale = H / h (1, 2, 4)."""
+    flow: index_to_flow(max_idx) of the matched LR features (or None: no pre-offset); scale = H / h (1, 2, 4).
+    The head's channels are computed in slices of 64-channel tiles + one 32-wide remainder (216 = 192 + 24) so that
+    no padded tile is multiplied."""
     srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
     B, _, H, W = srcs[0].shape
     Cin = sum(s.shape[1] for s in srcs)
@@ -299,29 +304,34 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
     if Cout != 3 * dg * 9:
         raise _lib.C2MError("conv3x3_dcn_head: weight must have 3*dg*9 output channels")
     dev = srcs[0].device
-    wr = _wcache.get(weight)
-    d = _lib.Conv3x3Desc()
-    d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
-    for k, s in enumerate(srcs):
-        d.src[k] = _nhwc_src(s, f"src{k}")
-    d.wr = wr.data_ptr()
     bias = _dev_f32(bias.detach(), "bias")
-    d.bias = bias.data_ptr()
-    d.out_mode = 3
     offset = torch.empty((B, 2 * dg * 9, H, W), dtype=torch.float32, device=dev)
     mask = torch.empty((B, dg * 9, H, W), dtype=torch.float32, device=dev)
-    d.out, d.mask_out, d.n_off, d.scale = offset.data_ptr(), mask.data_ptr(), 2 * dg * 9, int(scale)
     if flow is not None:
         if flow.dtype != torch.float32 or not flow.is_cuda or flow.dim() != 4 or flow.shape[0] != B or flow.shape[3] != 2:
             raise _lib.C2MError("flow must be float32 [B, fh, fw, 2] on the GPU")
         flow = flow.contiguous()
-        d.flow, d.fh, d.fw = flow.data_ptr(), flow.shape[1], flow.shape[2]
-    if abs_sum is not None:
-        if abs_sum.dtype != torch.float64 or abs_sum.numel() < 256 or not abs_sum.is_cuda:
-            raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
-        d.abs_sum = abs_sum.data_ptr()
-    with torch.cuda.device(dev):
-        _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
+    if abs_sum is not None and (abs_sum.dtype != torch.float64 or abs_sum.numel() < 256 or not abs_sum.is_cuda):
+        raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
+    split = (Cout // 64) * 64
+    slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
+    for (c0, c1) in slices:
+        wr = _wcache.get(weight, rows=(c0, c1))
+        d = _lib.Conv3x3Desc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, c1 - c0, len(srcs)
+        for k, s in enumerate(srcs):
+            d.src[k] = _nhwc_src(s, f"src{k}")
+        d.wr = wr.data_ptr()
+        d.bias = bias.data_ptr() + 4 * c0
+        d.out_mode = 3
+        d.out, d.mask_out, d.n_off, d.scale = offset.data_ptr(), mask.data_ptr(), 2 * dg * 9, int(scale)
+        d.cout_offset, d.cout_total = c0, Cout
+        if flow is not None:
+            d.flow, d.fh, d.fw = flow.data_ptr(), flow.shape[1], flow.shape[2]
+        if abs_sum is not None:
+            d.abs_sum = abs_sum.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
     return offset, mask
 

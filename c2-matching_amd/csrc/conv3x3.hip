@@ -79,6 +79,7 @@ struct Params {
   double* abs_sum;       // mode 3: C2M_ABS_SUM_SLOTS partial sums of |raw offset| or nullptr
   int out_vec4;          // mode 0: out / res pitches and bases are 16-byte aligned -> float4 stores
   int tpw;               // consecutive tiles per workgroup (>= 1)
+  int co_off, cout_total;// mode 3: this launch computes head channels [co_off, co_off + Cout) of cout_total
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -161,12 +162,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   // ------------------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * U * (MW * 32), (unsigned)U * WSLOT);
   const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
-  auto issue_w = [&](int gu) __attribute__((always_inline)) {   // gu: unit index in the workgroup's stream
-    const int u = gu % U;
-    const unsigned dst = w_base + (gu % 3) * WSLOT + wv * NW_W * 1024;   // U % 3 == 0: gu % 3 == u % 3
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 0, 0);
+  // units are issued strictly in stream order: `wsoff` is the byte offset of the next unit's image inside this cout block's
+  // weights (wraps after U units, once per tile); `slot` = ring slot of that unit (stream index % 3: a constant at every call
+  // site, because U % 3 == 0)
+  int wsoff = 0;
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {
+    const unsigned dst = w_base + slot * WSLOT + wv * NW_W * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 0, 0);
     if constexpr (NW_W == 2)   // the instruction offset advances BOTH the global and the LDS address
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, u * WSLOT, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 1024, 0);
+    wsoff += WSLOT;
+    if (wsoff == U * WSLOT) wsoff = 0;
   };
 
   auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
@@ -248,7 +254,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   auto load_ops = [&](unsigned ibuf, int t, int g, f32x4 (&a)[MT], f32x4& bq) __attribute__((always_inline)) {
     const int dy = t / 3, dx = t - 3 * dy;
     const int pl = (wv + dy) * HW_ + j + dx;
-    const unsigned baddr = ibuf + pl * 128 + ((((2 * g + hi) ^ (pl >> 1)) & 7) << 4);
+    // piece (2g + hi) ^ ((pl >> 1) & 7): the k-quad only flips bits 5-6 of the address -> one base per tap, one xor per quad
+    const unsigned baddr = (ibuf + pl * 128 + (((hi ^ (pl >> 1)) & 7) << 4)) ^ (unsigned)(g << 5);
     asm volatile("ds_read_b128 %0, %1" : "=v"(bq) : "v"(baddr) : "memory");
     // 9 % 3 == 0: tap t always sits in ring slot t % 3 (t is a constant after unrolling: the switch folds)
     if constexpr (MT == 2) {
@@ -301,11 +308,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   f32x4 a_s[2][MT], b_s[2];
   load_ops(in_base, 0, 0, a_s[0], b_s[0]);
   f32x4 res4[MT][4];
-  for (int gc = 0; gc < G; ++gc) {
-    const unsigned ibuf = in_base + (gc & 1) * IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * IN_BYTES;
-    const bool more_in = gc + 1 < G;
-    const int it = gc / p.nchunks;
-    const bool last_chunk = gc - it * p.nchunks == p.nchunks - 1;   // of its tile
+  for (int it = 0, gc = 0; it < ntl; ++it) {
     // MFMA-side tile (epilogue addresses)
     int b, y0, x0;
     tile_coords(tile_first + it, b, y0, x0);
@@ -313,6 +316,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     const bool pok = y < p.H && x < p.W;
     const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     const bool vec_res = MODE == 0 && p.out_vec4 && pok && (p.res1 || p.res2);
+   for (int c = 0; c < p.nchunks; ++c, ++gc) {
+    const unsigned ibuf = in_base + (gc & 1) * IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * IN_BYTES;
+    const bool more_in = gc + 1 < G;
+    const bool last_chunk = c == p.nchunks - 1;   // of its tile
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int gu = gc * 9 + t;
@@ -358,11 +365,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
         else wait_vmcnt<0>();
         // bare s_barrier: __syncthreads() would add a fence = s_waitcnt vmcnt(0) and drain DMAs that may stay in flight
         __builtin_amdgcn_s_barrier();
-        if (gu + 3 < 9 * G) issue_w(gu + 3);
+        if (gu + 3 < 9 * G) issue_w(t % 3);   // unit gu+3 -> the slot unit gu just vacated
         if (t == 8 && gc + 2 < G) issue_in(gc + 2);
       }
     }
-    if (!last_chunk) continue;
+   }   // chunks of the tile
     {   // + bias (LDS, one b128 per 4 consecutive channels)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -386,8 +393,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          const int co = co_lane + mt * 32 + 8 * qd;
-          if (co >= p.Cout || !pok) continue;
+          const int col = co_lane + mt * 32 + 8 * qd;   // channel inside this launch's slice
+          if (col >= p.Cout || !pok) continue;
+          const int co = col + p.co_off;                // channel of the whole head
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
@@ -413,10 +421,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
               p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
             }
           } else {
-            const int nm = p.Cout - p.n_off;
+            const int nm = p.cout_total - p.n_off;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (co + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
+              if (col + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
           }
         }
       if (p.abs_sum) {
@@ -562,7 +570,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   const bool out_vec4 = !(d->out_pix_pitch % 4 != 0 || d->out_row_pitch % 4 != 0 || d->out_img_pitch % 4 != 0 ||
                           ((uintptr_t)d->out & 15) || ((uintptr_t)d->res1 & 15) || ((uintptr_t)d->res2 & 15));
   if (d->out_mode == 1 && d->Cout % 4 != 0) return C2M_ERR_INVALID_ARG;
-  if (d->out_mode == 3 && (!d->mask_out || d->n_off <= 0 || d->n_off % 4 != 0 || d->n_off >= d->Cout || d->scale <= 0 ||
+  const int cout_total = d->cout_total > 0 ? d->cout_total : d->Cout;
+  if (d->out_mode == 3 && (!d->mask_out || d->n_off <= 0 || d->n_off % 4 != 0 || d->n_off >= cout_total || d->scale <= 0 ||
+                           d->cout_offset < 0 || d->cout_offset % 4 != 0 || d->cout_offset + d->Cout > cout_total ||
                            (d->flow && (d->fh <= 0 || d->fw <= 0))))
     return C2M_ERR_INVALID_ARG;
   if ((d->res1 || d->res2) && d->out_mode != 0) return C2M_ERR_UNSUPPORTED;
@@ -581,6 +591,8 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.res1 = d->res1; p.res2 = d->res2; p.mask_out = d->mask_out; p.flow = d->flow; p.fh = d->fh; p.fw = d->fw;
   p.scale = d->scale; p.n_off = d->n_off; p.abs_sum = d->abs_sum;
   p.out_vec4 = out_vec4 ? 1 : 0;
+  p.co_off = d->out_mode == 3 ? d->cout_offset : 0;
+  p.cout_total = cout_total;
 
   const int MW = conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;

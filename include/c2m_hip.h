@@ -203,6 +203,9 @@ typedef struct c2m_conv3x3_desc {
   int scale;               /* H / h: 1, 2 or 4 */
   int n_off;               /* offset channels = 2 * deformable_groups * 9 */
   double* abs_sum;         /* DCN_HEAD: C2M_ABS_SUM_SLOTS partial sums of |raw offset| (caller zeroes), or NULL */
+  int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
+  int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
+                              head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
 } c2m_conv3x3_desc;
 
 size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */

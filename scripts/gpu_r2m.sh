@@ -1,0 +1,4 @@
+mkdir -p gpurun_out/r2m
+timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -x -q 2>&1 | tail -12 > gpurun_out/r2m/pytest.log
+timeout 300 python scripts/bench_conv.py > gpurun_out/r2m/bench_conv_all.log 2>&1
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r2m/bench_default.log 2>&1
