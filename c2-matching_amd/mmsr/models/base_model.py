@@ -57,6 +57,12 @@ class BaseModel:
             return DataParallel(net)  # reference default without a launcher (base_model.py:73-74)
         return net
 
+    def validation(self, dataloader, current_iter, tb_logger, save_img=False):
+        """Dispatch as the reference does (base_model.py:44-58)."""
+        if self.opt.get('dist'):
+            return self.dist_validation(dataloader, current_iter, tb_logger, save_img)
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
     def get_bare_model(self, net):
         return unwrap(net)
 

@@ -3,6 +3,11 @@
 with the pixel loss / ``test``.  GAN, perceptual, texture losses, validation image I/O and LR schedulers are outside the
 hot path and are not provided here -- ``mmsr/train.py`` of the reference keeps using its own
 model file; this class is what bench/tests drive.
+
+Validation: ``nondist_validation`` computes PSNR / PSNR_Y / SSIM_Y with the reference's rules
+(ref_restoration_model.py:295-370) but on the device (mmsr/utils/metrics.py here: three scalars per image cross PCIe
+instead of two full images); ``dist_validation`` -- which in the reference calls a method that does not exist
+(sr_model.py:160-162) -- shards the loader over the ranks and all-reduces the sums.
 """
 import copy
 import logging
@@ -11,6 +16,7 @@ import torch
 
 import mmsr.models.networks as networks
 from mmsr.models.base_model import BaseModel, unwrap
+from mmsr.utils import metrics
 
 logger = logging.getLogger('base')
 
@@ -76,6 +82,59 @@ class RefRestorationModel(BaseModel):
         l_pix.backward()  # DCNv2 backward x3; DDP all-reduces net_g's gradients (RCCL) while it runs
         self.optimizer_g.step()
         self.log_dict['l_g_pix'] = l_pix.detach()  # no .item(): the reference's per-step host sync is dropped
+
+    # ---------------------------------------------------------------- validation
+    def _validate_shard(self, dataloader, rank, world):
+        """-> float64 tensor [psnr_sum, psnr_y_sum, ssim_y_sum, count] over items idx % world == rank."""
+        crop = self.opt.get('crop_border')
+        crop = self.opt.get('scale', 4) if crop is None else crop   # options.py:56-57
+        sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+        for idx, val_data in enumerate(dataloader):
+            if idx % world != rank:
+                continue
+            self.feed_data(val_data)
+            sr = self.test()
+            gt = self.gt
+            if val_data.get('padding', False) is not False and bool(torch.as_tensor(val_data['padding']).any()):
+                oh, ow = (int(torch.as_tensor(v).flatten()[0]) for v in val_data['original_size'][:2])
+                sr = sr[..., :oh, :ow]          # the reference crops only the SR image (:311-315); shapes must then agree
+                gt = gt[..., :oh, :ow]
+            m = metrics.validation_metrics(sr, gt, crop_border=crop)
+            sums[0] += m['psnr'].sum()
+            sums[1] += m['psnr_y'].sum()
+            sums[2] += m['ssim_y'].sum()
+            sums[3] += sr.shape[0]
+            del self.img_in_lq, self.output, self.gt   # as the reference: keep peak memory at one batch (:331-335)
+        return sums
+
+    def _report(self, sums, name, current_iter, tb_logger):
+        n = max(float(sums[3]), 1.0)
+        res = {'psnr': float(sums[0]) / n, 'psnr_y': float(sums[1]) / n, 'ssim_y': float(sums[2]) / n, 'count': int(sums[3])}
+        if self.rank <= 0:
+            logger.info(f"# Validation {name} # PSNR: {res['psnr']:.4e} # PSNR_Y: {res['psnr_y']:.4e} "
+                        f"# SSIM_Y: {res['ssim_y']:.4e}.")
+            if tb_logger:
+                for k in ('psnr', 'psnr_y', 'ssim_y'):
+                    tb_logger.add_scalar(k, res[k], current_iter)
+        return res
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        if save_img:
+            raise NotImplementedError('image writing is outside the hot path (SURVEY.md 2.1)')
+        name = getattr(getattr(dataloader, 'dataset', None), 'opt', {}).get('name', 'val')
+        return self._report(self._validate_shard(dataloader, 0, 1), name, current_iter, tb_logger)
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        """Every rank validates its share of the loader; one all-reduce (RCCL on the GPU, gloo in the CPU tests) of four
+        float64 sums gives every rank the dataset averages."""
+        if save_img:
+            raise NotImplementedError('image writing is outside the hot path (SURVEY.md 2.1)')
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        sums = self._validate_shard(dataloader, rank, world)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        name = getattr(getattr(dataloader, 'dataset', None), 'opt', {}).get('name', 'val')
+        return self._report(sums, name, current_iter, tb_logger)
 
     def test(self):
         self.net_g.eval()

@@ -189,3 +189,59 @@ def test_vgg_without_torchvision_says_weights_are_random(monkeypatch):
     from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
     with pytest.warns(RuntimeWarning, match='RANDOM weights'):
         VGGFeatureExtractor(['relu1_1'], 'vgg19')
+
+
+def _val_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p_ in (os.path.join(os.path.dirname(here), "c2-matching_amd"), os.path.join(here, "golden")):
+        sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmsr.models.ref_restoration_model import RefRestorationModel
+
+    class Fake(RefRestorationModel):   # validation logic only: no nets, SR = GT + a per-item perturbation
+        def __init__(self):
+            self.opt = {'dist': world > 1, 'scale': 4}
+            self.device = torch.device('cpu')
+            self.rank = rank
+            self.is_train = False
+
+        def feed_data(self, data):
+            self.gt = data['img_in']
+            self.img_in_lq = data['img_in_lq']
+            self.k = data['k']
+
+        def test(self):
+            self.output = (self.gt + 0.01 * (self.k + 1) * torch.sin(40 * self.gt)).clamp(0, 1)
+            return self.output
+
+    g = torch.Generator().manual_seed(0)
+    items = [{'img_in': torch.rand(1, 3, 40, 44, generator=g), 'img_in_lq': torch.zeros(1), 'k': k} for k in range(5)]
+    res = Fake().validation(items, 0, None, False)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_distributed_validation_equals_single_process():
+    """dist_validation (broken in the reference, sr_model.py:160-162) shards the loader over the ranks
+    and all-reduces the metric sums: world-2 gloo result == single-process result on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world, port in ((1, 29731), (2, 29732)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_val_worker, args=(r, world, port, q)) for r in range(world)]
+        [p.start() for p in procs]
+        got = [q.get(timeout=120) for _ in range(world)]
+        [p.join(60) for p in procs]
+        out[world] = dict(got)
+    single = out[1][0]
+    assert single['count'] == 5 and 20 < single['psnr'] < 60
+    for r in (0, 1):
+        for k in ('psnr', 'psnr_y', 'ssim_y'):
+            assert abs(out[2][r][k] - single[k]) < 1e-9, (r, k)
+        assert out[2][r]['count'] == 5
