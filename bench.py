@@ -129,7 +129,7 @@ def conv_roofline(kms_total, flops_total, n):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (outside the timed region, rank 0, N=1 only)
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None):
+def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None, gpu_idx=None):
     """ONE pair of the same batch through the same forward on the host cores (oracle/cpu_chain.py): stock torch-CPU
     convolutions, the reference's conv2d-filter correlation algorithm (ref_map_util.py:26-86), oracle pre-offsets and
     oracle DCNv2 (the reference has no CPU DCNv2).  ~10-20 s on the GPU box's cores."""
@@ -141,7 +141,7 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None):
     c2m_oracle.set_num_threads(min(threads, 64))
     tm = {}
     t0 = time.perf_counter()
-    sr, idx, _ = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm)
+    sr, idx, _ = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm, idx_for_offsets=gpu_idx)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"1 of the {lq.shape[0]} pairs of one step, whole forward (extractor, correlation as conv2d filters + "
@@ -274,6 +274,7 @@ def main():
     lq, up, ref = synth_images(B, h, dev, 1234 + rank)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
     it = [0]
+    last = {}
 
     @torch.no_grad()
     def restore_step():
@@ -286,6 +287,7 @@ def main():
         e[2].record()
         sr = net(lq, pre, ref_feat)
         e[3].record()
+        last["pre"] = pre
         return sr
 
     dt, prof, sr = timed(restore_step)
@@ -343,7 +345,11 @@ def main():
             "stage_ms": stage, "roofline": dominant, "roofline_kernels": rl, "configs1_corr_only": sub,
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, sr_cpu, _ = cpu_baseline_restore(ext, mp, net, lq, up, ref)
+            gpu_idx = last["pre"].max_idx[:1].cpu().numpy()
+            base, sr_cpu, idx_cpu = cpu_baseline_restore(ext, mp, net, lq, up, ref, gpu_idx=gpu_idx)
+            # parity of the timed GPU forward against the CPU chain on pair 0: index map (the CPU map comes from oneDNN
+            # convolutions of the extractor, so fp32 near-ties may flip) and SR pixels given the same index map
+            base["index_map_equal_fraction_gpu_vs_cpu_pair0"] = float((gpu_idx == idx_cpu).mean())
             base["sr_max_abs_diff_gpu_vs_cpu_pair0"] = float((sr[0].cpu() - sr_cpu[0]).abs().max())
             line["cpu_baseline"] = base
         print(json.dumps(line))

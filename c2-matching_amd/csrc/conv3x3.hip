@@ -603,12 +603,18 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
                            d->src[sidx].C) * 4;
     if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
   }
-  // tiles per workgroup: as many as keep >= 8 full rounds of 512 resident workgroups (2 per CU) -- long streams amortise the
-  // set-up and the first DMA wait, short launches stay balanced.  C2M_CONV_TPW overrides (experiments).
+  // tiles per workgroup: long streams amortise the set-up and the first DMA wait, but the launch is only as fast as its
+  // last round of 512 resident workgroups (2 per CU): take the tpw <= 10 with the fewest "rounds x tiles" (ties: the
+  // longer stream), e.g. 51200 tiles -> 10 (10 full rounds), 12800 -> 5 (5 full rounds).  C2M_CONV_TPW overrides.
   static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
   const int ncb = ceil_div(d->Cout, MW);
-  long long tpw = env_tpw > 0 ? env_tpw : (ntile * ncb) / (8 * 512);
-  tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+  long long tpw = 1, best = -1;
+  for (long long t = 1; t <= 10; ++t) {
+    const long long wgs = ((ntile + t - 1) / t) * ncb;
+    const long long cost = ((wgs + 511) / 512) * t;
+    if (best < 0 || cost <= best) { best = cost; tpw = t; }
+  }
+  if (env_tpw > 0) tpw = env_tpw;
   p.tpw = (int)tpw;
   dim3 grid((unsigned)((ntile + tpw - 1) / tpw), ncb);
   hipStream_t st = as_stream(stream);
