@@ -119,11 +119,15 @@ def dcn_roofline(name, B, C, Co, H, kms, n):
             "kernel_ms": kms, "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
-def conv_roofline(kms_total, flops_total, n):
+def conv_roofline(kms_total, flops_total, n, traffic=None):
+    """All conv3x3 launches of one step taken as one unit: FLOPs = sum of 2*Cout*9*Cin*H*W*B (SURVEY.md 8d applies the same
+    formula to the DCNv2 GEMMs), time = sum of the HIP-event kernel times, traffic = HBM bytes of those launches."""
     tf = flops_total / (kms_total * 1e-3) / 1e12 if kms_total > 0 else 0.0
-    return {"bound": "mfma", "kernel": "conv3x3_nhwc_mfma (all decoder / extractor convolutions of one step)",
+    return {"bound": "mfma", "kernel": "conv3x3_kernel<MT, MODE> (all fused channels-last 3x3 convolutions of one step: "
+                                       "decoder, offset heads, VGG19 taps, both extractor towers)",
             "achieved": tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MATRIX_PEAK_TFLOPS,
-            "traffic": None, "kernel_ms": kms_total, "launches_timed": n, "algorithmic_flops_per_launch": flops_total}
+            "traffic": traffic, "kernel_ms": kms_total, "launches_timed": n, "algorithmic_flops_per_launch": flops_total,
+            "per": "step (sum over the step's launches)"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -233,10 +237,13 @@ def main():
             dt = float(t.item())
         return dt, prof, out
 
-    traffic = None
-    tfile = os.path.join(REPO, "profiles", "corr_pmc_traffic.json")
+    # HBM bytes from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    # very command; gfx950 corrections applied by the summariser) -- valid for the default workload only
+    traffic, pmc = None, {}
+    tfile = os.path.join(REPO, "profiles", "step_pmc_traffic.json")
     if os.path.exists(tfile) and (B, h) == (16, 160):
-        traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        pmc = json.load(open(tfile))
+        traffic = pmc.get("corr_hbm_bytes_per_launch")
 
     # ---- configs[1] leg: correlation only on synthetic features (always run: sub-record of the default line) -------
     valid = (500 * h) // 640  # 500x500 Ref inside the 640x640 padded canvas, at feature scale
@@ -320,9 +327,12 @@ def main():
         dk = kern.get("dcn_v2_forward", [])
         layers = (("small", 256, h), ("medium", 128, 2 * h), ("large", 64, 4 * h))
         if dk and len(dk) % 3 == 0:   # launch order inside a step: small, medium, large (ref_restoration_arch.py:152-180)
+            dtraf = sorted(pmc.get("dcn_v2_forward_hbm_bytes_per_launch", {}).values())   # small < medium < large
             for k, (lname, ch, hh) in enumerate(layers):
                 mine = dk[k::3]
                 rl.append(dcn_roofline(lname, B, ch, ch, hh, sum(mine) / len(mine), len(mine)))
+                if len(dtraf) == 3:
+                    rl[-1]["traffic"] = dtraf[k]
             tot = sum(dk) / (len(dk) // 3)
             flops = sum(B * 2.0 * ch * 9 * ch * hh * hh for _, ch, hh in layers)
             rl.append({"bound": "mfma", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
@@ -332,7 +342,7 @@ def main():
                        "north_star_target": ">= 0.50 MFMA utilisation on DCNv2 forward at batch 16"})
         cv = kern.get("conv3x3_mfma", [])
         if cv:
-            rl.append(conv_roofline(sum(cv) / args.steps, conv_flops / args.steps, len(cv)))
+            rl.append(conv_roofline(sum(cv) / args.steps, conv_flops / args.steps, len(cv), pmc.get("conv3x3_hbm_bytes_per_step")))
         dominant = max(rl, key=lambda r: r["kernel_ms"]) if rl else None
         line = {
             "metric": METRIC, "value": B * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
