@@ -28,7 +28,7 @@ class Conv3x3Desc(ctypes.Structure):
                 ("wr", _vp), ("bias", _vp), ("act", _i), ("slope", ctypes.c_float), ("out_mode", _i), ("out", _vp),
                 ("out_pix_pitch", _i), ("out_row_pitch", _i), ("out_img_pitch", ctypes.c_longlong), ("res1", _vp),
                 ("res2", _vp), ("mask_out", _vp), ("flow", _vp), ("fh", _i), ("fw", _i), ("scale", _i), ("n_off", _i),
-                ("abs_sum", _vp), ("cout_offset", _i), ("cout_total", _i)]
+                ("abs_sum", _vp), ("algo", _i), ("cout_offset", _i), ("cout_total", _i)]
 
 
 class C2MError(RuntimeError):
@@ -65,6 +65,9 @@ def _declare(L):
     L.c2m_conv3x3_relayout_bytes.restype = _sz
     L.c2m_conv3x3_relayout_bytes.argtypes = [_i, _i]
     L.c2m_conv3x3_relayout_f32.argtypes = [_vp, _vp, _i, _i, _vp]
+    L.c2m_conv3x3_relayout_wino_bytes.restype = _sz
+    L.c2m_conv3x3_relayout_wino_bytes.argtypes = [_i, _i]
+    L.c2m_conv3x3_relayout_wino_f32.argtypes = [_vp, _vp, _i, _i, _vp]
     L.c2m_conv3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(Conv3x3Desc)]
     L.c2m_index_to_flow_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
 

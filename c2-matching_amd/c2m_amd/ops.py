@@ -182,9 +182,9 @@ class _WeightCache:
     def __init__(self):
         self._d = {}
 
-    def get(self, weight, pad_cin_to=None, rows=None):
+    def get(self, weight, pad_cin_to=None, rows=None, wino=False):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
-        slot = (id(weight), rows)
+        slot = (id(weight), rows, wino)
         hit = self._d.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -199,12 +199,14 @@ class _WeightCache:
             Ci = pad_cin_to
         w = w.contiguous()
         L = _lib.lib()
-        nbytes = L.c2m_conv3x3_relayout_bytes(Ci, Co)
+        nbytes = (L.c2m_conv3x3_relayout_wino_bytes if wino else L.c2m_conv3x3_relayout_bytes)(Ci, Co)
         if nbytes == 0:
-            raise _lib.C2MError(f"conv3x3: input channels must be a multiple of 32, got {Ci}")
+            raise _lib.C2MError(f"conv3x3: unsupported channel counts Cin={Ci}, Cout={Co}" + (" for the Winograd kernel" if wino else
+                                " (input channels must be a multiple of 32)"))
         wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(L.c2m_conv3x3_relayout_f32(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout_f32")
+            fn = L.c2m_conv3x3_relayout_wino_f32 if wino else L.c2m_conv3x3_relayout_f32
+            _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
         self._d[slot] = (key, wr)
         return wr
 
@@ -226,7 +228,18 @@ def empty_nhwc(B, C, H, W, device):
     return torch.empty((B, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
 
 
-def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None):
+import os as _os
+
+_WINO = _os.environ.get("C2M_CONV_WINO", "1") != "0"
+
+
+def _wino_ok(srcs, weight, out_mode, W):
+    """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 64-pixel tiles along x."""
+    return (_WINO and out_mode == "nhwc" and weight.shape[0] % 64 == 0 and W % 64 == 0 and
+            all(s.shape[1] % 16 == 0 for s in srcs) and sum(s.shape[1] for s in srcs) == weight.shape[1])
+
+
+def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
 
     srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
@@ -237,8 +250,10 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     Cin = sum(s.shape[1] for s in srcs)
     Cout = weight.shape[0]
     dev = srcs[0].device
-    wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None)
+    wino = _wino_ok(srcs, weight, out_mode, W) if algo is None else (algo == "winograd")
+    wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None, wino=wino)
     d = _lib.Conv3x3Desc()
+    d.algo = 1 if wino else 0
     d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
     for k, s in enumerate(srcs):
         if tuple(s.shape[2:]) != (H, W) or s.shape[0] != B:

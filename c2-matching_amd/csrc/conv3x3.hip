@@ -516,6 +516,280 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
   }
 }
 
+
+// =====================================================================================================================
+// Winograd F(2,3) along x (mode 0 only).  Output pixels are produced in horizontal PAIRS: for every row tap dy and the four
+// transform positions xi the kernel multiplies U[dy][xi] (= G g, precomputed: g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) with
+// V[dy][xi] (= B^T d: d0-d2, d1+d2, d2-d1, d1-d3 of the four input columns 2t-1 .. 2t+2) and accumulates M[xi] over
+// (dy, channels); the pair is Y0 = M0+M1+M2, Y1 = M1-M2-M3.  12 instead of 18 MFMA k-steps per output pair: 1.5x fewer
+// matrix instructions, paid with 0.5 VALU instruction per MFMA for the input transform (formed in registers from four
+// b128 reads per row tap and k-quad, shared by the four xi units) and a 128-instruction combine per tile.  Same machinery
+// as the direct kernel: buffer-addressed LDS-DMA with hardware zero fill, weight images in a ring (here 4 KiB units of
+// 16 channels, 6 slots, 5 units ahead), b128 operand reads with hand-placed waits, persistent tiles.
+//   workgroup = 4 waves = 64 x 4 pixels; wave w = row w; lane (hi, j) = pixel pair j (x0 + 2j, x0 + 2j + 1)
+//   chunk = 16 input channels (64-byte pixel rows in LDS, pieces swizzled by (pixel >> 2) & 3; the stride-2 pair access
+//   leaves a 2-way conflict on the 8 raw reads per 64 MFMAs), unit = (chunk, dy, xi) = 16 MFMAs per wave
+// fp32 throughout; results differ from the direct kernel by the rounding of the transforms (tested at 2e-5 * scale).
+// =====================================================================================================================
+namespace wino {
+constexpr int PW = 32;                         // pixel pairs per wave
+constexpr int TWX = 2 * PW, THY = 4;           // pixel tile of a workgroup
+constexpr int HWc = TWX + 2, HHr = THY + 2;    // halo tile 66 x 6
+constexpr int NPIX = HWc * HHr;                // 396 pixels
+constexpr int KC = 16;                         // channels per chunk
+constexpr int NIN_REAL = (NPIX * 4 + 63) / 64; // 25 DMA instructions per halo tile
+constexpr int NIN_W = 7;
+constexpr int IN_BYTES = NIN_REAL * 1024;      // 25600
+constexpr int WUNIT = 64 * 64;                 // bytes of a unit's weight image: 64 couts x 16 k
+constexpr int NRING = 6;
+constexpr int UPC = 12;                        // units per chunk: 3 row taps x 4 transform positions
+static_assert(UPC % NRING == 0, "ring slot of a unit must be a compile-time constant");
+}  // namespace wino
+
+// weights W[Cout][Cin][3][3] -> Wr[cb][chunk][dy][xi][row 64][slot 4][e 4], slot = q ^ ((row >> 2) & 3),
+// value = U[cb*64 + row][chunk*16 + 4q + e][dy][xi] (0 beyond Cout)
+__global__ void __launch_bounds__(256) conv3x3_relayout_wino_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                                      long long total, float* __restrict__ wr) {
+  const long long e0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e0 >= total) return;
+  const int e = (int)(e0 & 3), slot = (int)((e0 >> 2) & 3);
+  long long r = e0 >> 4;
+  const int row = (int)(r & 63); r >>= 6;
+  const int xi = (int)(r & 3); r >>= 2;
+  const int dy = (int)(r % 3); r /= 3;
+  const int nch = Cin / wino::KC;
+  const int chunk = (int)(r % nch);
+  const int cb = (int)(r / nch);
+  const int q = slot ^ ((row >> 2) & 3);
+  const int co = cb * 64 + row, ci = chunk * wino::KC + 4 * q + e;
+  float u = 0.0f;
+  if (co < Cout) {
+    const float* g = w + ((size_t)co * Cin + ci) * 9 + dy * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    u = xi == 0 ? g0 : xi == 1 ? ((g0 + g1) + g2) * 0.5f : xi == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+  }
+  wr[e0] = u;
+}
+
+__global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
+  constexpr int MT = 2;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  // [in0 | in1 | w ring x6 | dummy 1 KiB | bias 64 floats]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned in_base = lds0, w_base = lds0 + 2 * wino::IN_BYTES, dummy = w_base + wino::NRING * wino::WUNIT, bias_lds = dummy + 1024;
+
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = p.tiles_x * p.tiles_y * p.B;
+  const int tile_first = xcd_remap(blockIdx.x, gridDim.x) * p.tpw;
+  const int ntl = min(p.tpw, ntile - tile_first);
+  const int cb = blockIdx.y;
+  const int UT = p.nchunks * wino::UPC;                    // units per tile
+  const int G = ntl * p.nchunks;                     // chunks of this workgroup
+  const int T = G * wino::UPC;                             // units of this workgroup
+
+  // ---- DMA plumbing (see conv3x3_kernel): weights
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * UT * (wino::WUNIT / 4), (unsigned)UT * wino::WUNIT);
+  const unsigned wvoff = (wv * 64 + l) * 16;
+  int wsoff = 0;
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(w_base + slot * wino::WUNIT + wv * 1024),
+                                             16, wvoff, wsoff, 0, 0);
+    wsoff += wino::WUNIT;
+    if (wsoff == UT * wino::WUNIT) wsoff = 0;
+  };
+  // ---- halo tile: instruction n = wave + 4 * slot covers pieces [64n, 64n + 64): pixel pl = 16n + (lane >> 2), LDS slot
+  //      lane & 3, logical piece q = slot ^ ((pl >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+    b = tile / (p.tiles_x * p.tiles_y);
+    x0 = tx * wino::TWX;
+    y0 = ty * wino::THY;
+  };
+  unsigned ivoff[wino::NIN_W];
+  int ib = 0, iy0 = 0, ix0 = 0;
+  __amdgpu_buffer_rsrc_t rs0, rs1;
+  const int qdma = (l & 3) ^ ((l >> 4) & 3);
+  auto set_source = [&](const Src& S) __attribute__((always_inline)) {
+    int ry = 0, rx = 16 * wv + (l >> 2);
+#pragma unroll
+    for (int sl = 0; sl < wino::NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
+      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+      const bool ok = n < wino::NIN_REAL && ry < wino::HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * qdma) * 4u : kOOB;
+      rx += 64;
+      if (rx >= wino::HWc) { rx -= wino::HWc; ry += 1; }
+    }
+  };
+  auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
+    const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
+    return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
+  };
+  auto issue_in = [&](int gc) __attribute__((always_inline)) {
+    const int it = gc / p.nchunks, c0 = (gc - it * p.nchunks) * wino::KC;
+    const bool first = c0 < p.src[0].C;
+    if (c0 == 0) {
+      tile_coords(tile_first + it, ib, iy0, ix0);
+      rs0 = src_rsrc(p.src[0], ib);
+      rs1 = src_rsrc(p.src[1], ib);
+      set_source(p.src[0]);
+    } else if (c0 == p.src[0].C) {
+      set_source(p.src[1]);
+    }
+    const unsigned buf = in_base + (gc & 1) * wino::IN_BYTES;
+    const int soff = (first ? c0 : c0 - p.src[0].C) * 4;
+#pragma unroll
+    for (int sl = 0; sl < wino::NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
+      const unsigned dst = n < wino::NIN_REAL ? buf + n * 1024 : dummy;
+      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
+    }
+  };
+
+  const int co_lane = cb * 64 + 4 * hi;
+  if (tid < 64) {
+    const int co = cb * 64 + tid;
+    *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+  }
+  f32x16 M[4][MT];
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) M[xi][mt][r] = 0.0f;
+
+  // A operand: row = cout j (+32 mt), piece 2g + hi, slot q ^ ((row >> 2) & 3); + ring slot * 4096 + mt * 2048 as offsets
+  unsigned aaddr[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) aaddr[g] = w_base + j * 64 + (((2 * g + hi) ^ ((j >> 2) & 3)) << 4);
+  auto load_a = [&](int uc, int g, f32x4 (&a)[MT]) __attribute__((always_inline)) {   // uc: unit inside the chunk (constant)
+    switch (uc % wino::NRING) {
+      case 0: asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      case 1: asm volatile("ds_read_b128 %0, %2 offset:4096\n\tds_read_b128 %1, %2 offset:6144" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      case 2: asm volatile("ds_read_b128 %0, %2 offset:8192\n\tds_read_b128 %1, %2 offset:10240" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      case 3: asm volatile("ds_read_b128 %0, %2 offset:12288\n\tds_read_b128 %1, %2 offset:14336" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      case 4: asm volatile("ds_read_b128 %0, %2 offset:16384\n\tds_read_b128 %1, %2 offset:18432" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      default: asm volatile("ds_read_b128 %0, %2 offset:20480\n\tds_read_b128 %1, %2 offset:22528" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+    }
+  };
+  auto wait_a = [&](auto n, f32x4 (&a)[MT]) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+  };
+  // input transform of row tap dy for both k-quads: four raw b128 reads per quad -> V[xi][g]
+  f32x4 V[4][2];
+  auto transform = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
+    f32x4 d[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bcol = 0; bcol < 4; ++bcol) {
+        const int pl = (wv + dy) * wino::HWc + 2 * j + bcol;
+        const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]),
+                 "+v"(d[1][2]), "+v"(d[1][3]));
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      V[0][g] = d[g][0] - d[g][2];
+      V[1][g] = d[g][1] + d[g][2];
+      V[2][g] = d[g][2] - d[g][1];
+      V[3][g] = d[g][1] - d[g][3];
+    }
+  };
+
+  issue_in(0);
+  if (G > 1) issue_in(1);
+#pragma unroll
+  for (int s = 0; s < wino::NRING; ++s) issue_w(s);   // T >= 12 > wino::NRING
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 a_s[2][MT];
+  load_a(0, 0, a_s[0]);
+  int in_age = 100;   // units since the last halo-tile DMA was issued (it stays "young" for 4 units, see the waits)
+  for (int it = 0, gc = 0; it < ntl; ++it) {
+    int b, y0, x0;
+    tile_coords(tile_first + it, b, y0, x0);
+    const int y = y0 + wv, x = x0 + 2 * j;
+    const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
+    const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
+    for (int c = 0; c < p.nchunks; ++c, ++gc) {
+      const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES;
+#pragma unroll
+      for (int uc = 0; uc < wino::UPC; ++uc) {
+        const int gu = gc * wino::UPC + uc;
+        const int dy = uc >> 2, xi = uc & 3;
+        if (xi == 0) transform(ibuf, dy);   // (also waits for the A reads already in flight: lgkmcnt(0))
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int cur = g, nxt = g ^ 1;
+          bool fetched = true;
+          if (g == 0) load_a(uc, 1, a_s[nxt]);
+          else if (gu + 1 < T) load_a(uc + 1, 0, a_s[nxt]);   // (uc + 1) % 6: next unit's ring slot, also across chunks (12 % 6 == 0)
+          else fetched = false;
+          if (fetched) wait_a(std::integral_constant<int, 2>(), a_s[cur]);
+          else wait_a(std::integral_constant<int, 0>(), a_s[cur]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              M[xi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[cur][mt][e], V[xi][g][e], M[xi][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (gu + 1 < T) {
+          // W(gu+2) must have landed; younger DMAs that may keep flying: W(gu+3 .. gu+5) as far as they exist, and the halo
+          // tile issued right after W(e+6) at the end of unit e while gu <= e + 4
+          const int yw = min(3, max(0, T - 3 - gu));
+          const bool yin = in_age <= 3;
+          if (yin) {
+            if (yw == 3) wait_vmcnt<3 + wino::NIN_W>(); else if (yw == 2) wait_vmcnt<2 + wino::NIN_W>();
+            else if (yw == 1) wait_vmcnt<1 + wino::NIN_W>(); else wait_vmcnt<wino::NIN_W>();
+          } else {
+            if (yw == 3) wait_vmcnt<3>(); else if (yw == 2) wait_vmcnt<2>(); else if (yw == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+          }
+          __builtin_amdgcn_s_barrier();
+          if (gu + wino::NRING < T) issue_w(uc % wino::NRING);   // unit gu+6 -> the slot unit gu just vacated
+          ++in_age;
+          if (uc == wino::UPC - 1 && gc + 2 < G) { issue_in(gc + 2); in_age = 0; }
+        }
+      }
+    }
+    // ---- tile epilogue: Y0 = M0 + M1 + M2 -> M[0], Y1 = M1 - M2 - M3 -> M[3]; + bias, activation, residuals, store
+    const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
+    const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
+    float* ob = p.out + opix + co_lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int co = co_lane + mt * 32 + 8 * qd;
+        const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (mt * 32 + 8 * qd + 4 * hi) * 4);
+        f32x4 y0v, y1v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m0 = M[0][mt][4 * qd + e], m1 = M[1][mt][4 * qd + e], m2 = M[2][mt][4 * qd + e], m3 = M[3][mt][4 * qd + e];
+          y0v[e] = ((m0 + m1) + m2) + bv[e];
+          y1v[e] = ((m1 - m2) - m3) + bv[e];
+          if (p.act == 1) { y0v[e] = fmaxf(y0v[e], 0.0f); y1v[e] = fmaxf(y1v[e], 0.0f); }
+          else if (p.act == 2) { y0v[e] = fmaxf(y0v[e], y0v[e] * p.slope); y1v[e] = fmaxf(y1v[e], y1v[e] * p.slope); }
+          M[0][mt][4 * qd + e] = 0.0f; M[1][mt][4 * qd + e] = 0.0f; M[2][mt][4 * qd + e] = 0.0f; M[3][mt][4 * qd + e] = 0.0f;
+        }
+        if (pok && co + 3 < p.Cout) {
+          const int o = mt * 32 + 8 * qd;
+          if (r1) { y0v += *reinterpret_cast<const f32x4*>(r1 + o); y1v += *reinterpret_cast<const f32x4*>(r1 + p.out_pix_pitch + o); }
+          if (r2) { y0v += *reinterpret_cast<const f32x4*>(r2 + o); y1v += *reinterpret_cast<const f32x4*>(r2 + p.out_pix_pitch + o); }
+          *reinterpret_cast<f32x4*>(ob + o) = y0v;
+          *reinterpret_cast<f32x4*>(ob + p.out_pix_pitch + o) = y1v;
+        }
+      }
+  }
+}
+
 }  // namespace conv
 }  // namespace c2m
 
@@ -546,6 +820,21 @@ extern "C" int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight
   return check_launch();
 }
 
+extern "C" size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % conv::wino::KC != 0 || Cout % 64 != 0) return 0;
+  return (size_t)(Cout / 64) * (Cin / conv::wino::KC) * conv::wino::UPC * conv::wino::WUNIT;
+}
+
+extern "C" int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr) {
+  if (!weight || !wr) return C2M_ERR_INVALID_ARG;
+  const size_t bytes = c2m_conv3x3_relayout_wino_bytes(Cin, Cout);
+  if (bytes == 0) return C2M_ERR_UNSUPPORTED;
+  const long long total = (long long)(bytes / 4);
+  hipLaunchKernelGGL(conv::conv3x3_relayout_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     weight, Cin, Cout, total, wr);
+  return check_launch();
+}
+
 extern "C" int c2m_index_to_flow_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int hq, int wq, float* flow) {
   if (!max_idx || !flow || B <= 0 || hq <= 0 || wq <= 0) return C2M_ERR_INVALID_ARG;
   const int n = B * hq * wq;
@@ -558,9 +847,13 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   if (!d || !d->wr || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->nsrc < 1 ||
       d->nsrc > 2 || !d->src[0].ptr || (d->nsrc == 2 && !d->src[1].ptr))
     return C2M_ERR_INVALID_ARG;
+  const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X;
+  if (d->algo != 0 && !wino) return C2M_ERR_INVALID_ARG;
+  if (wino && (d->out_mode != 0 || d->Cout % 64 != 0 || d->W % 2 != 0)) return C2M_ERR_UNSUPPORTED;
+  const int kch = wino ? conv::wino::KC : conv::KCH;
   int csum = 0;
   for (int s = 0; s < d->nsrc; ++s) {
-    if (d->src[s].C <= 0 || d->src[s].C % conv::KCH != 0 || d->src[s].pix_pitch % 4 != 0 || d->src[s].row_pitch % 4 != 0 ||
+    if (d->src[s].C <= 0 || d->src[s].C % kch != 0 || d->src[s].pix_pitch % 4 != 0 || d->src[s].row_pitch % 4 != 0 ||
         d->src[s].img_pitch % 4 != 0 || ((uintptr_t)d->src[s].ptr & 15))
       return C2M_ERR_UNSUPPORTED;   // 16-byte pieces: every pitch a multiple of 4 floats, 32-channel chunks
     csum += d->src[s].C;
@@ -579,7 +872,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
 
   conv::Params p;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
-  p.tiles_x = ceil_div(d->W, conv::TW); p.tiles_y = ceil_div(d->H, conv::TH); p.nchunks = d->Cin / conv::KCH;
+  p.tiles_x = ceil_div(d->W, wino ? conv::wino::TWX : conv::TW);
+  p.tiles_y = ceil_div(d->H, conv::TH);
+  p.nchunks = d->Cin / kch;
   for (int s = 0; s < 2; ++s) {
     const int k = s < d->nsrc ? s : 0;
     p.src[s].ptr = d->src[k].ptr; p.src[s].C = s < d->nsrc ? d->src[k].C : 0; p.src[s].pix_pitch = d->src[k].pix_pitch;
@@ -594,8 +889,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.co_off = d->out_mode == 3 ? d->cout_offset : 0;
   p.cout_total = cout_total;
 
-  const int MW = conv_mw(d->Cout);
+  const int MW = wino ? 64 : conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
+  if (wino && !out_vec4) return C2M_ERR_UNSUPPORTED;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
   if (d->act == C2M_ACT_LEAKY_RELU && !(d->slope >= 0.0f && d->slope <= 1.0f)) return C2M_ERR_UNSUPPORTED;   // max(v, slope*v)
   for (int sidx = 0; sidx < d->nsrc; ++sidx) {   // 32-bit byte offsets inside one sample (buffer addressing)
@@ -626,7 +922,12 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
   };
   static unsigned long long done[2][4] = {};
-  if (MW == 64) {
+  if (wino) {
+    static unsigned long long done_w = 0;
+    const size_t ldsw = 2 * conv::wino::IN_BYTES + conv::wino::NRING * conv::wino::WUNIT + 1024 + 256;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel), ldsw, done_w)) != C2M_OK) return rc;
+    hipLaunchKernelGGL(conv::conv3x3_wino_kernel, grid, dim3(256), ldsw, st, p);
+  } else if (MW == 64) {
     switch (d->out_mode) {
       case 0: go(&conv::conv3x3_kernel<2, 0>, done[1][0]); break;
       case 1: go(&conv::conv3x3_kernel<2, 1>, done[1][1]); break;

@@ -178,3 +178,32 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
         assert got_e[k].is_contiguous() and got_e[k].shape == want_e[k].shape
         err = float((got_e[k] - want_e[k].detach()).abs().max())
         assert err < 2e-4 * max(1.0, float(want_e[k].abs().max())), (k, err)
+
+
+WINO_CASES = [
+    # B, [Cin per source], Cout, H, W, act, n residuals     (W % 64 == 0, Cout % 64 == 0, channels % 16 == 0)
+    (2, [64], 64, 12, 64, 1, 0),
+    (1, [64], 64, 9, 128, 0, 2),
+    (2, [64, 64], 64, 8, 64, 2, 0),      # two sources (head_large: cat(x, swapped))
+    (1, [96], 128, 6, 64, 0, 1),         # 6 chunks of 16, two cout blocks
+    (1, [64], 64, 40, 320, 1, 1),        # several tiles per workgroup stream
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_matches_fp64_and_direct(ops, dev, case):
+    """Winograd F(2,3)-along-x kernel (what ops.conv3x3 picks for 64-wide-tileable maps) against float64 conv2d and against
+    the direct kernel: same fp32 products up to the rounding of the input / weight transforms -> 2e-5 * scale."""
+    B, cins, Cout, H, W, act, nres = case
+    xs = [_cl(_rand((B, c, H, W), dev, 110 + k)) for k, c in enumerate(cins)]
+    w = _rand((Cout, sum(cins), 3, 3), dev, 120, 1.0 / np.sqrt(9 * sum(cins)))
+    b = _rand((Cout,), dev, 121)
+    res = [_cl(_rand((B, Cout, H, W), dev, 130 + k)) for k in range(nres)]
+    kw = dict(act=act, slope=0.1, res1=res[0] if nres > 0 else None, res2=res[1] if nres > 1 else None)
+    got = ops.conv3x3(xs, w, b, algo="winograd", **kw)
+    direct = ops.conv3x3(xs, w, b, algo="direct", **kw)
+    want = _ref(xs, w, b, act, 0.1, res)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got.double() - want).abs().max()) < 2e-5 * scale
+    assert float((got - direct).abs().max()) < 2e-5 * scale
+    assert float((direct.double() - want).abs().max()) < 1e-5 * scale
