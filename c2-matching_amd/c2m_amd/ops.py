@@ -164,14 +164,15 @@ def dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, kernel_taps, abs_s
 # 3x3 convolution, channels-last, fused epilogue (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-_conv_flops = [0.0]
+_conv_flops = [0.0, 0.0]   # algorithmic (direct-convolution) flops, flops the MFMAs actually execute
 
 
-def conv_flops_of_last_steps(reset=True):
-    """2*Cout*9*Cin*H*W*B summed over the conv3x3 calls since the last reset (bench.py's roofline line)."""
-    v = _conv_flops[0]
+def conv_flops_of_last_steps(reset=True, executed=False):
+    """2*Cout*9*Cin*H*W*B summed over the conv3x3 calls since the last reset (bench.py's roofline line); executed=True: the
+    flops the matrix instructions really perform (Winograd F(2,3) launches execute 2/3 of the direct count)."""
+    v = _conv_flops[1 if executed else 0]
     if reset:
-        _conv_flops[0] = 0.0
+        _conv_flops[0] = _conv_flops[1] = 0.0
     return v
 
 
@@ -290,6 +291,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
+    _conv_flops[1] += 2.0 * Cout * (6 if wino else 9) * Cin * H * W * B
     return out
 
 
@@ -348,6 +350,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
+    _conv_flops[1] += 2.0 * Cout * 9 * Cin * H * W * B
     return offset, mask
 
 

@@ -679,10 +679,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     constexpr int N = decltype(n)::value;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
   };
-  // input transform of row tap dy for both k-quads: four raw b128 reads per quad -> V[xi][g]
-  f32x4 V[4][2];
-  auto transform = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
-    f32x4 d[2][4];
+  // input transform of one row tap for both k-quads: four raw b128 reads per quad (input columns 2j-1 .. 2j+2 of the
+  // lane's pair) -> V[xi][g].  The raw reads of the next group (chunk, dy) are issued in the last step of the current
+  // group's last unit (in place of that step's operand prefetch); at the top of the next unit the operand read is issued
+  // first and the 32 transform instructions run under its latency.
+  f32x4 V[4][2], d[2][4];
+  auto issue_raw = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -691,8 +693,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
         const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
       }
+  };
+  auto wait_raw = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]),
                  "+v"(d[1][2]), "+v"(d[1][3]));
+  };
+  auto vcomp = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       V[0][g] = d[g][0] - d[g][2];
@@ -710,7 +716,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   __builtin_amdgcn_s_barrier();
 
   f32x4 a_s[2][MT];
-  load_a(0, 0, a_s[0]);
+  issue_raw(in_base, 0);
   int in_age = 100;   // units since the last halo-tile DMA was issued (it stays "young" for 4 units, see the waits)
   for (int it = 0, gc = 0; it < ntl; ++it) {
     int b, y0, x0;
@@ -719,21 +725,37 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
     const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES;
+      const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * wino::IN_BYTES;
 #pragma unroll
       for (int uc = 0; uc < wino::UPC; ++uc) {
         const int gu = gc * wino::UPC + uc;
         const int dy = uc >> 2, xi = uc & 3;
-        if (xi == 0) transform(ibuf, dy);   // (also waits for the A reads already in flight: lgkmcnt(0))
+        const bool next_group = gu + 4 - xi < T;   // a group (chunk, dy) follows this one
+        if (xi == 0) {   // raw values landed (issued in the previous unit's last step / before the loop): operands, then transform
+          wait_raw();
+          load_a(uc, 0, a_s[0]);
+          vcomp();
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const int cur = g, nxt = g ^ 1;
-          bool fetched = true;
-          if (g == 0) load_a(uc, 1, a_s[nxt]);
-          else if (gu + 1 < T) load_a(uc + 1, 0, a_s[nxt]);   // (uc + 1) % 6: next unit's ring slot, also across chunks (12 % 6 == 0)
-          else fetched = false;
-          if (fetched) wait_a(std::integral_constant<int, 2>(), a_s[cur]);
-          else wait_a(std::integral_constant<int, 0>(), a_s[cur]);
+          if (g == 0) {
+            load_a(uc, 1, a_s[nxt]);
+            wait_a(std::integral_constant<int, 2>(), a_s[cur]);
+          } else if (xi == 3) {
+            // last step of the group: fetch the next group's raw values instead of the next unit's operands (those are read at
+            // the top of the next unit, under the transform): next row tap of this chunk, or row tap 0 of the next chunk
+            if (next_group) {
+              if (dy < 2) issue_raw(ibuf, dy + 1);
+              else issue_raw(ibuf_next, 0);
+              wait_a(std::integral_constant<int, 8>(), a_s[cur]);
+            } else {
+              wait_a(std::integral_constant<int, 0>(), a_s[cur]);
+            }
+          } else {
+            load_a(uc + 1, 0, a_s[nxt]);
+            wait_a(std::integral_constant<int, 2>(), a_s[cur]);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
