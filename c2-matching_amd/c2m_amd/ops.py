@@ -235,8 +235,8 @@ _WINO = _os.environ.get("C2M_CONV_WINO", "1") != "0"
 
 
 def _wino_ok(srcs, weight, out_mode, W):
-    """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 64-pixel tiles along x."""
-    return (_WINO and out_mode == "nhwc" and weight.shape[0] % 64 == 0 and W % 64 == 0 and
+    """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 64- (or 32-) pixel tiles along x."""
+    return (_WINO and out_mode == "nhwc" and weight.shape[0] % 64 == 0 and W % 32 == 0 and
             all(s.shape[1] % 16 == 0 for s in srcs) and sum(s.shape[1] for s in srcs) == weight.shape[1])
 
 

@@ -526,20 +526,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
 // b128 reads per row tap and k-quad, shared by the four xi units) and a 128-instruction combine per tile.  Same machinery
 // as the direct kernel: buffer-addressed LDS-DMA with hardware zero fill, weight images in a ring (here 4 KiB units of
 // 16 channels, 6 slots, 5 units ahead), b128 operand reads with hand-placed waits, persistent tiles.
-//   workgroup = 4 waves = 64 x 4 pixels; wave w = row w; lane (hi, j) = pixel pair j (x0 + 2j, x0 + 2j + 1)
+//   workgroup = 4 waves = 64 x 4 pixels (wave = row, lane (hi, j) = pixel pair j) or 32 x 8 (wave = two rows of 16 pairs)
 //   chunk = 16 input channels (64-byte pixel rows in LDS, pieces swizzled by (pixel >> 2) & 3; the stride-2 pair access
 //   leaves a 2-way conflict on the 8 raw reads per 64 MFMAs), unit = (chunk, dy, xi) = 16 MFMAs per wave
 // fp32 throughout; results differ from the direct kernel by the rounding of the transforms (tested at 2e-5 * scale).
 // =====================================================================================================================
 namespace wino {
-constexpr int PW = 32;                         // pixel pairs per wave
-constexpr int TWX = 2 * PW, THY = 4;           // pixel tile of a workgroup
-constexpr int HWc = TWX + 2, HHr = THY + 2;    // halo tile 66 x 6
-constexpr int NPIX = HWc * HHr;                // 396 pixels
 constexpr int KC = 16;                         // channels per chunk
-constexpr int NIN_REAL = (NPIX * 4 + 63) / 64; // 25 DMA instructions per halo tile
-constexpr int NIN_W = 7;
-constexpr int IN_BYTES = NIN_REAL * 1024;      // 25600
+constexpr int NIN_W = 7;                       // halo DMA instructions per wave (25 of 28 used by the 66 x 6 tile, 22 by 34 x 10)
+constexpr int IN_BYTES = 25 * 1024;            // halo buffer: 396 pixels x 64 B, rounded up to whole DMA instructions
 constexpr int WUNIT = 64 * 64;                 // bytes of a unit's weight image: 64 couts x 16 k
 constexpr int NRING = 6;
 constexpr int UPC = 12;                        // units per chunk: 3 row taps x 4 transform positions
@@ -571,7 +566,15 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_wino_kernel(const float*
   wr[e0] = u;
 }
 
+// PX = pixel pairs per wave row: 32 -> workgroup tile 64 x 4 pixels (wave = one row), 16 -> 32 x 8 (wave = two rows of 16 pairs;
+// for maps whose width is a multiple of 32 but not of 64, e.g. the 160-wide LR-scale layers)
+template <int PX>
 __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
+  constexpr int RW = 32 / PX;                      // pixel rows per wave
+  constexpr int TWX = 2 * PX, THY = 4 * RW;        // pixel tile of a workgroup
+  constexpr int HWc = TWX + 2, HHr = THY + 2;      // halo tile
+  constexpr int NIN_REAL = (HWc * HHr * 4 + 63) / 64;
+  static_assert(NIN_REAL <= 4 * wino::NIN_W && NIN_REAL * 1024 <= wino::IN_BYTES, "halo tile must fit the DMA plan / LDS buffer");
   constexpr int MT = 2;
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   // [in0 | in1 | w ring x6 | dummy 1 KiB | bias 64 floats]
@@ -580,6 +583,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = j & (PX - 1), prow = wv * RW + j / PX;   // the lane's pixel pair inside the tile: columns 2pt, 2pt+1 of row prow
   const int ntile = p.tiles_x * p.tiles_y * p.B;
   const int tile_first = xcd_remap(blockIdx.x, gridDim.x) * p.tpw;
   const int ntl = min(p.tpw, ntile - tile_first);
@@ -603,23 +607,25 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
     b = tile / (p.tiles_x * p.tiles_y);
-    x0 = tx * wino::TWX;
-    y0 = ty * wino::THY;
+    x0 = tx * TWX;
+    y0 = ty * THY;
   };
   unsigned ivoff[wino::NIN_W];
   int ib = 0, iy0 = 0, ix0 = 0;
   __amdgpu_buffer_rsrc_t rs0, rs1;
   const int qdma = (l & 3) ^ ((l >> 4) & 3);
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
-    int ry = 0, rx = 16 * wv + (l >> 2);
+    const int pl0 = 16 * wv + (l >> 2);
+    int ry = pl0 / HWc, rx = pl0 - ry * HWc;
 #pragma unroll
     for (int sl = 0; sl < wino::NIN_W; ++sl) {
       const int n = wv + 4 * sl;
       const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-      const bool ok = n < wino::NIN_REAL && ry < wino::HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const bool ok = n < NIN_REAL && ry < HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * qdma) * 4u : kOOB;
-      rx += 64;
-      if (rx >= wino::HWc) { rx -= wino::HWc; ry += 1; }
+      rx += 64;   // next slot: 64 pixels on (at most two row wraps: 64 < 2 * HWc)
+      if (rx >= HWc) { rx -= HWc; ry += 1; }
+      if (rx >= HWc) { rx -= HWc; ry += 1; }
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
@@ -642,7 +648,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
 #pragma unroll
     for (int sl = 0; sl < wino::NIN_W; ++sl) {
       const int n = wv + 4 * sl;
-      const unsigned dst = n < wino::NIN_REAL ? buf + n * 1024 : dummy;
+      const unsigned dst = n < NIN_REAL ? buf + n * 1024 : dummy;
       if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
     }
@@ -689,7 +695,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int bcol = 0; bcol < 4; ++bcol) {
-        const int pl = (wv + dy) * wino::HWc + 2 * j + bcol;
+        const int pl = (prow + dy) * HWc + 2 * pt + bcol;
         const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
       }
@@ -721,7 +727,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   for (int it = 0, gc = 0; it < ntl; ++it) {
     int b, y0, x0;
     tile_coords(tile_first + it, b, y0, x0);
-    const int y = y0 + wv, x = x0 + 2 * j;
+    const int y = y0 + prow, x = x0 + 2 * pt;
     const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
     const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
@@ -871,7 +877,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     return C2M_ERR_INVALID_ARG;
   const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X;
   if (d->algo != 0 && !wino) return C2M_ERR_INVALID_ARG;
-  if (wino && (d->out_mode != 0 || d->Cout % 64 != 0 || d->W % 2 != 0)) return C2M_ERR_UNSUPPORTED;
+  if (wino && (d->out_mode != 0 || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
   const int kch = wino ? conv::wino::KC : conv::KCH;
   int csum = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -894,8 +900,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
 
   conv::Params p;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
-  p.tiles_x = ceil_div(d->W, wino ? conv::wino::TWX : conv::TW);
-  p.tiles_y = ceil_div(d->H, conv::TH);
+  const bool wino64 = wino && d->W % 64 == 0;     // 64 x 4 tiles; otherwise (W % 32 == 0) 32 x 8 tiles
+  p.tiles_x = ceil_div(d->W, wino ? (wino64 ? 64 : 32) : conv::TW);
+  p.tiles_y = ceil_div(d->H, wino && !wino64 ? 8 : conv::TH);
   p.nchunks = d->Cin / kch;
   for (int s = 0; s < 2; ++s) {
     const int k = s < d->nsrc ? s : 0;
@@ -945,10 +952,15 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   };
   static unsigned long long done[2][4] = {};
   if (wino) {
-    static unsigned long long done_w = 0;
+    static unsigned long long done_w[2] = {};
     const size_t ldsw = 2 * conv::wino::IN_BYTES + conv::wino::NRING * conv::wino::WUNIT + 1024 + 256;
-    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel), ldsw, done_w)) != C2M_OK) return rc;
-    hipLaunchKernelGGL(conv::conv3x3_wino_kernel, grid, dim3(256), ldsw, st, p);
+    if (wino64) {
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel<32>), ldsw, done_w[0])) != C2M_OK) return rc;
+      hipLaunchKernelGGL(conv::conv3x3_wino_kernel<32>, grid, dim3(256), ldsw, st, p);
+    } else {
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel<16>), ldsw, done_w[1])) != C2M_OK) return rc;
+      hipLaunchKernelGGL(conv::conv3x3_wino_kernel<16>, grid, dim3(256), ldsw, st, p);
+    }
   } else if (MW == 64) {
     switch (d->out_mode) {
       case 0: go(&conv::conv3x3_kernel<2, 0>, done[1][0]); break;

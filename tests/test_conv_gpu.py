@@ -181,12 +181,14 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
 
 
 WINO_CASES = [
-    # B, [Cin per source], Cout, H, W, act, n residuals     (W % 64 == 0, Cout % 64 == 0, channels % 16 == 0)
+    # B, [Cin per source], Cout, H, W, act, n residuals     (W % 32 == 0, Cout % 64 == 0, channels % 16 == 0)
     (2, [64], 64, 12, 64, 1, 0),
     (1, [64], 64, 9, 128, 0, 2),
     (2, [64, 64], 64, 8, 64, 2, 0),      # two sources (head_large: cat(x, swapped))
     (1, [96], 128, 6, 64, 0, 1),         # 6 chunks of 16, two cout blocks
     (1, [64], 64, 40, 320, 1, 1),        # several tiles per workgroup stream
+    (2, [64], 64, 21, 160, 1, 1),        # width % 64 != 0: the 32 x 8 tile variant (LR-scale layers), ragged tile rows
+    (1, [64, 256], 256, 16, 96, 2, 0),   # small_offset_conv1 geometry on 32-wide tiles
 ]
 
 
