@@ -524,20 +524,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
 // (dy, channels); the pair is Y0 = M0+M1+M2, Y1 = M1-M2-M3.  12 instead of 18 MFMA k-steps per output pair: 1.5x fewer
 // matrix instructions, paid with 0.5 VALU instruction per MFMA for the input transform (formed in registers from four
 // b128 reads per row tap and k-quad, shared by the four xi units) and a 128-instruction combine per tile.  Same machinery
-// as the direct kernel: buffer-addressed LDS-DMA with hardware zero fill, weight images in a ring (here 4 KiB units of
-// 16 channels, 6 slots, 5 units ahead), b128 operand reads with hand-placed waits, persistent tiles.
+// as the direct kernel: buffer-addressed LDS-DMA with hardware zero fill, 8 KiB weight units in a ring of 3 (two units
+// ahead), b128 operand reads with hand-placed waits, persistent tiles.
 //   workgroup = 4 waves = 64 x 4 pixels (wave = row, lane (hi, j) = pixel pair j) or 32 x 8 (wave = two rows of 16 pairs)
 //   chunk = 16 input channels (64-byte pixel rows in LDS, pieces swizzled by (pixel >> 2) & 3; the stride-2 pair access
-//   leaves a 2-way conflict on the 8 raw reads per 64 MFMAs), unit = (chunk, dy, xi) = 16 MFMAs per wave
+//   leaves a 2-way conflict on the 8 raw reads per 64 MFMAs), unit = (chunk, dy, two xi) = 32 MFMAs per wave
 // fp32 throughout; results differ from the direct kernel by the rounding of the transforms (tested at 2e-5 * scale).
 // =====================================================================================================================
 namespace wino {
 constexpr int KC = 16;                         // channels per chunk
 constexpr int NIN_W = 7;                       // halo DMA instructions per wave (25 of 28 used by the 66 x 6 tile, 22 by 34 x 10)
 constexpr int IN_BYTES = 25 * 1024;            // halo buffer: 396 pixels x 64 B, rounded up to whole DMA instructions
-constexpr int WUNIT = 64 * 64;                 // bytes of a unit's weight image: 64 couts x 16 k
-constexpr int NRING = 6;
-constexpr int UPC = 12;                        // units per chunk: 3 row taps x 4 transform positions
+constexpr int WIMG = 64 * 64;                  // bytes of one (dy, xi) weight image: 64 couts x 16 k
+constexpr int WUNIT = 2 * WIMG;                // a unit = two transform positions of one row tap: 8 KiB, 32 MFMAs per wave
+constexpr int NRING = 3;
+constexpr int UPC = 6;                         // units per chunk: 3 row taps x 2 pairs of transform positions
 static_assert(UPC % NRING == 0, "ring slot of a unit must be a compile-time constant");
 }  // namespace wino
 
@@ -594,11 +595,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
 
   // ---- DMA plumbing (see conv3x3_kernel): weights
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * UT * (wino::WUNIT / 4), (unsigned)UT * wino::WUNIT);
-  const unsigned wvoff = (wv * 64 + l) * 16;
+  const unsigned wvoff = (wv * 128 + l) * 16;
   int wsoff = 0;
   auto issue_w = [&](int slot) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(w_base + slot * wino::WUNIT + wv * 1024),
-                                             16, wvoff, wsoff, 0, 0);
+    const unsigned dst = w_base + slot * wino::WUNIT + wv * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 1024, 0);
     wsoff += wino::WUNIT;
     if (wsoff == UT * wino::WUNIT) wsoff = 0;
   };
@@ -671,14 +673,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   unsigned aaddr[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) aaddr[g] = w_base + j * 64 + (((2 * g + hi) ^ ((j >> 2) & 3)) << 4);
-  auto load_a = [&](int uc, int g, f32x4 (&a)[MT]) __attribute__((always_inline)) {   // uc: unit inside the chunk (constant)
-    switch (uc % wino::NRING) {
-      case 0: asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+  auto load_a = [&](int uc, int st, f32x4 (&a)[MT]) __attribute__((always_inline)) {   // uc: unit inside the chunk, st: step = 2 * xi_local + g
+    const int g = st & 1;
+    switch ((uc % wino::NRING) * 2 + (st >> 1)) {
+      case 0: asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
       case 1: asm volatile("ds_read_b128 %0, %2 offset:4096\n\tds_read_b128 %1, %2 offset:6144" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
       case 2: asm volatile("ds_read_b128 %0, %2 offset:8192\n\tds_read_b128 %1, %2 offset:10240" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
       case 3: asm volatile("ds_read_b128 %0, %2 offset:12288\n\tds_read_b128 %1, %2 offset:14336" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
       case 4: asm volatile("ds_read_b128 %0, %2 offset:16384\n\tds_read_b128 %1, %2 offset:18432" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
-      default: asm volatile("ds_read_b128 %0, %2 offset:20480\n\tds_read_b128 %1, %2 offset:22528" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      case 5: asm volatile("ds_read_b128 %0, %2 offset:20480\n\tds_read_b128 %1, %2 offset:22528" : "=&v"(a[0]), "=&v"(a[1]) : "v"(aaddr[g]) : "memory"); break;
+      default: break;
     }
   };
   auto wait_a = [&](auto n, f32x4 (&a)[MT]) __attribute__((always_inline)) {
@@ -716,14 +720,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
 
   issue_in(0);
   if (G > 1) issue_in(1);
-#pragma unroll
-  for (int s = 0; s < wino::NRING; ++s) issue_w(s);   // T >= 12 > wino::NRING
+  issue_w(0);
+  issue_w(1);
+  issue_w(2);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  // Synchronisation as in conv3x3_kernel: at the top of unit gu the weight units gu and gu+1 and the halo tile of chunk gc
+  // (from unit 2 of a chunk on: of chunk gc+1) are visible, W(gu+2) is in flight; the barrier at the end of unit gu
+  // publishes W(gu+2) and frees ring slot gu % 3 for W(gu+3).
   f32x4 a_s[2][MT];
   issue_raw(in_base, 0);
-  int in_age = 100;   // units since the last halo-tile DMA was issued (it stays "young" for 4 units, see the waits)
   for (int it = 0, gc = 0; it < ntl; ++it) {
     int b, y0, x0;
     tile_coords(tile_first + it, b, y0, x0);
@@ -732,23 +739,25 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * wino::IN_BYTES;
+      const bool more_in = gc + 1 < G;
 #pragma unroll
       for (int uc = 0; uc < wino::UPC; ++uc) {
         const int gu = gc * wino::UPC + uc;
-        const int dy = uc >> 2, xi = uc & 3;
-        const bool next_group = gu + 4 - xi < T;   // a group (chunk, dy) follows this one
-        if (xi == 0) {   // raw values landed (issued in the previous unit's last step / before the loop): operands, then transform
+        const int dy = uc >> 1, xh = uc & 1;          // row tap, which half of the transform positions (xi = 2 xh, 2 xh + 1)
+        const bool next_group = gu + 2 - xh < T;       // a group (chunk, dy) follows this one
+        if (xh == 0) {   // raw values landed (issued in the previous group's last step / before the loop): operands, then transform
           wait_raw();
           load_a(uc, 0, a_s[0]);
           vcomp();
         }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int cur = g, nxt = g ^ 1;
-          if (g == 0) {
-            load_a(uc, 1, a_s[nxt]);
+        for (int st = 0; st < 4; ++st) {               // step = (xi_local, g)
+          const int cur = st & 1, nxt = cur ^ 1;
+          const int xi = 2 * xh + (st >> 1), g = st & 1;
+          if (st < 3) {
+            load_a(uc, st + 1, a_s[nxt]);
             wait_a(std::integral_constant<int, 2>(), a_s[cur]);
-          } else if (xi == 3) {
+          } else if (xh == 1) {
             // last step of the group: fetch the next group's raw values instead of the next unit's operands (those are read at
             // the top of the next unit, under the transform): next row tap of this chunk, or row tap 0 of the next chunk
             if (next_group) {
@@ -759,7 +768,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
               wait_a(std::integral_constant<int, 0>(), a_s[cur]);
             }
           } else {
-            load_a(uc + 1, 0, a_s[nxt]);
+            load_a(uc + 1, 0, a_s[nxt]);               // next unit of the same group
             wait_a(std::integral_constant<int, 2>(), a_s[cur]);
           }
 #pragma unroll
@@ -770,20 +779,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (gu + 1 < T) {
-          // W(gu+2) must have landed; younger DMAs that may keep flying: W(gu+3 .. gu+5) as far as they exist, and the halo
-          // tile issued right after W(e+6) at the end of unit e while gu <= e + 4
-          const int yw = min(3, max(0, T - 3 - gu));
-          const bool yin = in_age <= 3;
-          if (yin) {
-            if (yw == 3) wait_vmcnt<3 + wino::NIN_W>(); else if (yw == 2) wait_vmcnt<2 + wino::NIN_W>();
-            else if (yw == 1) wait_vmcnt<1 + wino::NIN_W>(); else wait_vmcnt<wino::NIN_W>();
-          } else {
-            if (yw == 3) wait_vmcnt<3>(); else if (yw == 2) wait_vmcnt<2>(); else if (yw == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
-          }
+          // W(gu+2) was issued one unit ago and is the youngest DMA in flight -- except at unit 0 of chunks >= 1, where the halo
+          // tile of chunk gc+1 was issued right after it (end of the previous chunk's last unit) and may keep flying
+          if (uc == 0 && gc >= 1 && more_in) wait_vmcnt<wino::NIN_W>();
+          else wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
-          if (gu + wino::NRING < T) issue_w(uc % wino::NRING);   // unit gu+6 -> the slot unit gu just vacated
-          ++in_age;
-          if (uc == wino::UPC - 1 && gc + 2 < G) { issue_in(gc + 2); in_age = 0; }
+          if (gu + 3 < T) issue_w(uc % wino::NRING);   // unit gu+3 -> the slot unit gu just vacated
+          if (uc == wino::UPC - 1 && gc + 2 < G) issue_in(gc + 2);
         }
       }
     }
@@ -850,7 +852,7 @@ extern "C" int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight
 
 extern "C" size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % conv::wino::KC != 0 || Cout % 64 != 0) return 0;
-  return (size_t)(Cout / 64) * (Cin / conv::wino::KC) * conv::wino::UPC * conv::wino::WUNIT;
+  return (size_t)(Cout / 64) * (Cin / conv::wino::KC) * 12 * conv::wino::WIMG;   // 3 row taps x 4 transform positions
 }
 
 extern "C" int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr) {
