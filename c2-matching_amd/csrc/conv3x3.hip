@@ -126,6 +126,44 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 constexpr unsigned kOOB = 0x80000000u;   // voffset of a lane that must read zeros (>= any num_records used here)
 
+// DCN offset/mask head, one group of 4 consecutive head channels of one pixel (used by both convolution kernels).
+// Channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s: P_k[y][x] =
+// s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid.  `col` = channel inside this
+// launch's slice, v = conv + bias.  Returns the |raw offset| contribution for the reference's offset-mean warning.
+__device__ __forceinline__ float dcn_head_store(const Params& p, int b, int y, int x, int col, const f32x4& v) {
+  const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
+  const int co = col + p.co_off;                // channel of the whole head
+  float asum = 0.0f;
+  if (co < p.n_off) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int gt = (co >> 1) + h2, tap = gt % 9;
+      const int ki = tap / 3, kj = tap - 3 * ki;
+      float fy = 0.0f, fx = 0.0f;
+      if (p.flow) {
+        const int ys = y - p.scale * ki, xs = x - p.scale * kj;
+        if (ys >= 0 && xs >= 0) {
+          const int yy = ys / p.scale, xx = xs / p.scale;
+          if (yy < p.fh && xx < p.fw) {
+            const float2 f = reinterpret_cast<const float2*>(p.flow)[((size_t)b * p.fh + yy) * p.fw + xx];
+            fx = f.x * (float)p.scale;
+            fy = f.y * (float)p.scale;
+          }
+        }
+      }
+      asum += fabsf(v[2 * h2]) + fabsf(v[2 * h2 + 1]);
+      p.out[((size_t)b * p.n_off + co + 2 * h2) * HWs + pix] = v[2 * h2] + fy;
+      p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
+    }
+  } else {
+    const int nm = p.cout_total - p.n_off;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
+  }
+  return asum;
+}
+
 // MODE = Params::out_mode (compile time: each store flavour is its own kernel, the others' code is not even loaded)
 //
 // A workgroup processes p.tpw consecutive tiles as ONE continuous stream of chunks and units: the halo tile of the next
@@ -385,47 +423,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     // epilogue of the tile (bias is already inside acc); the accumulators restart from the bias for the next tile
     // ----------------------------------------------------------------------------------------------------------------
     if constexpr (MODE == 3) {
-      // DCN offset/mask head: channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s:
-      // P_k[y][x] = s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid
       float asum = 0.0f;
-      const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const int col = co_lane + mt * 32 + 8 * qd;   // channel inside this launch's slice
           if (col >= p.Cout || !pok) continue;
-          const int co = col + p.co_off;                // channel of the whole head
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
-          if (co < p.n_off) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-              const int gt = (co >> 1) + h2, tap = gt % 9;
-              const int ki = tap / 3, kj = tap - 3 * ki;
-              float fy = 0.0f, fx = 0.0f;
-              if (p.flow) {
-                const int ys = y - p.scale * ki, xs = x - p.scale * kj;
-                if (ys >= 0 && xs >= 0) {
-                  const int yy = ys / p.scale, xx = xs / p.scale;
-                  if (yy < p.fh && xx < p.fw) {
-                    const float2 f = reinterpret_cast<const float2*>(p.flow)[((size_t)b * p.fh + yy) * p.fw + xx];
-                    fx = f.x * (float)p.scale;
-                    fy = f.y * (float)p.scale;
-                  }
-                }
-              }
-              asum += fabsf(v[2 * h2]) + fabsf(v[2 * h2 + 1]);
-              p.out[((size_t)b * p.n_off + co + 2 * h2) * HWs + pix] = v[2 * h2] + fy;
-              p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
-            }
-          } else {
-            const int nm = p.cout_total - p.n_off;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (col + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
-          }
+          asum += dcn_head_store(p, b, y, x, col, v);
         }
       if (p.abs_sum) {
 #pragma unroll
@@ -569,7 +577,7 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_wino_kernel(const float*
 
 // PX = pixel pairs per wave row: 32 -> workgroup tile 64 x 4 pixels (wave = one row), 16 -> 32 x 8 (wave = two rows of 16 pairs;
 // for maps whose width is a multiple of 32 but not of 64, e.g. the 160-wide LR-scale layers)
-template <int PX>
+template <int PX, int MODE>   // MODE 0: channels-last (+ activation, residuals); MODE 3: DCN offset/mask head
 __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   constexpr int RW = 32 / PX;                      // pixel rows per wave
   constexpr int TWX = 2 * PX, THY = 4 * RW;        // pixel tile of a workgroup
@@ -732,11 +740,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   f32x4 a_s[2][MT];
   issue_raw(in_base, 0);
   for (int it = 0, gc = 0; it < ntl; ++it) {
-    int b, y0, x0;
-    tile_coords(tile_first + it, b, y0, x0);
-    const int y = y0 + prow, x = x0 + 2 * pt;
-    const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
-    const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * wino::IN_BYTES;
       const bool more_in = gc + 1 < G;
@@ -789,10 +792,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
         }
       }
     }
-    // ---- tile epilogue: Y0 = M0 + M1 + M2 -> M[0], Y1 = M1 - M2 - M3 -> M[3]; + bias, activation, residuals, store
+    // ---- tile epilogue: Y0 = M0 + M1 + M2 -> pixel x, Y1 = M1 - M2 - M3 -> pixel x + 1; + bias, then the mode's store
+    // (pixel coordinates are derived here, not at the top of the tile: nothing of the epilogue stays live across the units)
+    int b, y0, x0;
+    tile_coords(tile_first + it, b, y0, x0);
+    asm volatile("" : "+s"(b), "+s"(y0), "+s"(x0));
+    const int y = y0 + prow, x = x0 + 2 * pt;
+    const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
+    const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
     const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
     const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
     float* ob = p.out + opix + co_lane;
+    float asum = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -805,11 +816,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
           const float m0 = M[0][mt][4 * qd + e], m1 = M[1][mt][4 * qd + e], m2 = M[2][mt][4 * qd + e], m3 = M[3][mt][4 * qd + e];
           y0v[e] = ((m0 + m1) + m2) + bv[e];
           y1v[e] = ((m1 - m2) - m3) + bv[e];
-          if (p.act == 1) { y0v[e] = fmaxf(y0v[e], 0.0f); y1v[e] = fmaxf(y1v[e], 0.0f); }
-          else if (p.act == 2) { y0v[e] = fmaxf(y0v[e], y0v[e] * p.slope); y1v[e] = fmaxf(y1v[e], y1v[e] * p.slope); }
+          if constexpr (MODE == 0) {
+            if (p.act == 1) { y0v[e] = fmaxf(y0v[e], 0.0f); y1v[e] = fmaxf(y1v[e], 0.0f); }
+            else if (p.act == 2) { y0v[e] = fmaxf(y0v[e], y0v[e] * p.slope); y1v[e] = fmaxf(y1v[e], y1v[e] * p.slope); }
+          }
           M[0][mt][4 * qd + e] = 0.0f; M[1][mt][4 * qd + e] = 0.0f; M[2][mt][4 * qd + e] = 0.0f; M[3][mt][4 * qd + e] = 0.0f;
         }
-        if (pok && co + 3 < p.Cout) {
+        if constexpr (MODE == 3) {
+          if (pok && co < p.Cout) {
+            asum += dcn_head_store(p, b, y, x, co, y0v);
+            asum += dcn_head_store(p, b, y, x + 1, co, y1v);
+          }
+        } else if (pok && co + 3 < p.Cout) {
           const int o = mt * 32 + 8 * qd;
           if (r1) { y0v += *reinterpret_cast<const f32x4*>(r1 + o); y1v += *reinterpret_cast<const f32x4*>(r1 + p.out_pix_pitch + o); }
           if (r2) { y0v += *reinterpret_cast<const f32x4*>(r2 + o); y1v += *reinterpret_cast<const f32x4*>(r2 + p.out_pix_pitch + o); }
@@ -817,6 +835,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
           *reinterpret_cast<f32x4*>(ob + p.out_pix_pitch + o) = y1v;
         }
       }
+    if (MODE == 3 && p.abs_sum) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
+      if (l == 0) atomicAdd(p.abs_sum + ((blockIdx.x * 4 + wv + blockIdx.y * 31 + it) & (C2M_ABS_SUM_SLOTS - 1)), (double)asum);
+    }
   }
 }
 
@@ -879,7 +902,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     return C2M_ERR_INVALID_ARG;
   const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X;
   if (d->algo != 0 && !wino) return C2M_ERR_INVALID_ARG;
-  if (wino && (d->out_mode != 0 || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
+  if (wino && ((d->out_mode != 0 && d->out_mode != 3) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
   const int kch = wino ? conv::wino::KC : conv::KCH;
   int csum = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -922,7 +945,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
 
   const int MW = wino ? 64 : conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
-  if (wino && !out_vec4) return C2M_ERR_UNSUPPORTED;
+  if (wino && d->out_mode == 0 && !out_vec4) return C2M_ERR_UNSUPPORTED;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
   if (d->act == C2M_ACT_LEAKY_RELU && !(d->slope >= 0.0f && d->slope <= 1.0f)) return C2M_ERR_UNSUPPORTED;   // max(v, slope*v)
   for (int sidx = 0; sidx < d->nsrc; ++sidx) {   // 32-bit byte offsets inside one sample (buffer addressing)
@@ -954,14 +977,16 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   };
   static unsigned long long done[2][4] = {};
   if (wino) {
-    static unsigned long long done_w[2] = {};
+    static unsigned long long done_w[2][2] = {};
     const size_t ldsw = 2 * conv::wino::IN_BYTES + conv::wino::NRING * conv::wino::WUNIT + 1024 + 256;
-    if (wino64) {
-      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel<32>), ldsw, done_w[0])) != C2M_OK) return rc;
-      hipLaunchKernelGGL(conv::conv3x3_wino_kernel<32>, grid, dim3(256), ldsw, st, p);
+    auto gow = [&](auto kern, unsigned long long& dn) {
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsw, dn)) != C2M_OK) return;
+      hipLaunchKernelGGL(kern, grid, dim3(256), ldsw, st, p);
+    };
+    if (d->out_mode == 3) {
+      if (wino64) gow(&conv::conv3x3_wino_kernel<32, 3>, done_w[0][1]); else gow(&conv::conv3x3_wino_kernel<16, 3>, done_w[1][1]);
     } else {
-      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::conv3x3_wino_kernel<16>), ldsw, done_w[1])) != C2M_OK) return rc;
-      hipLaunchKernelGGL(conv::conv3x3_wino_kernel<16>, grid, dim3(256), ldsw, st, p);
+      if (wino64) gow(&conv::conv3x3_wino_kernel<32, 0>, done_w[0][0]); else gow(&conv::conv3x3_wino_kernel<16, 0>, done_w[1][0]);
     }
   } else if (MW == 64) {
     switch (d->out_mode) {

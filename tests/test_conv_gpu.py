@@ -114,8 +114,10 @@ def test_dcn_head_matches_oracle_assembly(ops, dev):
     same index map (corres_generation_arch.py:69-109): offsets/mask within conv tolerance, pre-offset part exact."""
     import c2m_oracle as oracle
     import synth
-    B, C, h, w, dg = 2, 64, 12, 14, 8
-    for s in (1, 2, 4):
+    B, C, dg = 2, 64, 8
+    # w = 14: every scale on the direct kernel; w = 16: 32- / 64-pixel-wide maps at scales 2 / 4 take the Winograd kernel for the
+    # 192-channel slice of the head (+ the direct kernel for the remaining 24 channels)
+    for (h, w, s) in ((12, 14, 1), (12, 14, 2), (12, 14, 4), (12, 16, 1), (12, 16, 2), (12, 16, 4)):
         H, W = h * s, w * s
         feat = _cl(_rand((B, C, H, W), dev, 60 + s))
         wt, bs = _rand((3 * dg * 9, C, 3, 3), dev, 61, 0.02), _rand((3 * dg * 9,), dev, 62, 0.1)
@@ -131,7 +133,7 @@ def test_dcn_head_matches_oracle_assembly(ops, dev):
         pre_t = torch.from_numpy(pre).to(dev).double().flip(-1).permute(0, 1, 4, 2, 3).reshape(B, 18, H, W).repeat(1, dg, 1, 1)
         want_abs = float(want_off.abs().sum())
         want_off = want_off + pre_t
-        tol = 1e-5 * max(1.0, float(raw.abs().max()))
+        tol = 2e-5 * max(1.0, float(raw.abs().max()))
         assert float((off.double() - want_off).abs().max()) < tol
         assert float((msk.double() - torch.sigmoid(m)).abs().max()) < 1e-6
         assert abs(float(abs_sum.sum()) - want_abs) < 1e-4 * want_abs
