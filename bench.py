@@ -86,15 +86,25 @@ def build_models(dev, seed=1234):
 # ---------------------------------------------------------------------------------------------------------------------
 # work models
 # ---------------------------------------------------------------------------------------------------------------------
-def corr_executed_flops(B, C, h):
-    """MFMA flops the correlation sweep actually issues (tiles incl. halo / quantisation), per launch."""
+def corr_executed_flops(B, C, h, swept_rows=None):
+    """MFMA flops the correlation sweep actually issues (tiles incl. halo / quantisation), per launch.  swept_rows = ref
+    pixel rows swept, summed over samples and x-tiles (less than B * x_tiles * h when duplicate rows were eliminated)."""
     tiles = ((h - 2 + 13) // 14) ** 2
-    steps = ((h - 2 + 27) // 28) * h
-    return B * tiles * (steps + 1) * 8 * (C // 2) * (2 * 32 * 32 * 2)
+    if swept_rows is None:
+        swept_rows = B * ((h - 2 + 27) // 28) * h
+    return tiles * (swept_rows + B) * 8 * (C // 2) * (2 * 32 * 32 * 2)
 
 
-def corr_roofline(B, C, h, kms, n, traffic):
-    exec_flops = corr_executed_flops(B, C, h)
+def corr_swept_rows(h):
+    """(rows swept, rows of the full sweep) of the most recent correlation launch, from the kernel's own skip table."""
+    from c2m_amd import ops
+    tab = ops.last_corr_skip_table().cpu()
+    full = tab.shape[0] * tab.shape[1] * h
+    return int(full - (tab[..., 1] - tab[..., 0]).sum().item()), full
+
+
+def corr_roofline(B, C, h, kms, n, traffic, swept=None):
+    exec_flops = corr_executed_flops(B, C, h, swept[0] if swept else None)
     useful = B * 2.0 * (h * h) ** 2 * C                      # pixel-level products D[p][r]: the restructured minimum
     algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9             # SURVEY.md 8d: 2*Nq*Nr*C*9 per pair
     tf = lambda f: f / (kms * 1e-3) / 1e12 if kms > 0 else 0.0  # noqa: E731
@@ -108,7 +118,12 @@ def corr_roofline(B, C, h, kms, n, traffic):
             "frac_useful_flops": tf(useful) / FP32_MATRIX_PEAK_TFLOPS,
             "frac_sec8d_algorithmic": tf(algo) / FP32_MATRIX_PEAK_TFLOPS,
             "executed_flops_per_launch": exec_flops, "useful_flops_per_launch": useful,
-            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": tf(algo)}
+            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": tf(algo),
+            "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None,
+            "duplicate_row_elimination": "ref rows that repeat the three rows above them bit for bit (the zero-padding band "
+                                         "of a 500x500 Ref) are not swept: their patches tie with an earlier, lower-index "
+                                         "patch and can never be the reference's first maximum.  Exact; data-dependent "
+                                         "(no such rows -> full sweep)"}
 
 
 def dcn_roofline(name, B, C, Co, H, kms, n):
@@ -263,6 +278,7 @@ def main():
     if args.workload == "corr":
         dt, prof, out = timed(corr_step)
         assert int(out[0].min()) >= 0 and int(out[0].max()) < (h - 2) ** 2
+        swept = corr_swept_rows(h)
         if rank == 0:
             kern = [ms for (name, ms) in prof if name == "corr_argmax_mfma"]
             kms = sum(kern) / max(len(kern), 1)
@@ -273,7 +289,7 @@ def main():
                     "config": {"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), feature "
                                            "normalise + 3x3 correlation/arg-max index map + pre-offset maps (NO DCNv2 / decoder)",
                                "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
-                    "roofline": corr_roofline(B, C, h, kms, len(kern), traffic)}
+                    "roofline": corr_roofline(B, C, h, kms, len(kern), traffic, swept)}
             if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline_corr(h, C)
             print(json.dumps(line))
@@ -304,6 +320,7 @@ def main():
 
     dt, prof, sr = timed(restore_step)
     conv_flops, conv_flops_exec = timed.conv_flops, timed.conv_flops_exec
+    swept = corr_swept_rows(h)   # of the timed steps' correlation launch (same inputs every step)
     assert tuple(sr.shape) == (B, 3, 4 * h, 4 * h) and bool(torch.isfinite(sr).all())
     stage = {"extractor": 0.0, "correspondence": 0.0, "restoration": 0.0}
     for e in ev[args.warmup:]:
@@ -328,7 +345,7 @@ def main():
         rl = []
         ck = kern.get("corr_argmax_mfma", [])
         if ck:
-            rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), traffic))
+            rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), traffic, swept))
         dk = kern.get("dcn_v2_forward", [])
         layers = (("small", 256, h), ("medium", 128, 2 * h), ("large", 64, 4 * h))
         if dk and len(dk) % 3 == 0:   # launch order inside a step: small, medium, large (ref_restoration_arch.py:152-180)

@@ -38,9 +38,10 @@ def feature_normalize(x):
 
 
 def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
-                                norm_input=False, force_generic=False):
+                                norm_input=False, force_generic=False, return_skip=False):
     """Batched ref_map_util.feature_match_index: feat_in [B,C,Hq,Wq], feat_ref [B,C,Hr,Wr] ->
-    (max_idx int64 [B,Hqp,Wqp], max_val float32 [B,Hqp,Wqp])."""
+    (max_idx int64 [B,Hqp,Wqp], max_val float32 [B,Hqp,Wqp]).  return_skip=True appends the MFMA kernel's duplicate-row
+    table, int32 [B, x_tiles, 2] = (from, to) per (sample, ref x-tile) (c2m_feature_match_skip_table; diagnostics)."""
     fi, fr = _dev_f32(feat_in, "feat_in"), _dev_f32(feat_ref, "feat_ref")
     if fi.dim() != 4 or fr.dim() != 4 or fi.shape[:2] != fr.shape[:2] or fi.device != fr.device:
         raise _lib.C2MError("feat_in / feat_ref must be [B,C,H,W] with equal B, C and device")
@@ -60,7 +61,28 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
                                                  sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
                                                  idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes),
                    "c2m_feature_match_index_f32")
+        global _last_corr
+        _last_corr = (ws, (B, Hq, Wq, Hr, Wr))
+        if return_skip:
+            return idx, val, last_corr_skip_table()
     return idx, val
+
+
+_last_corr = None
+
+
+def last_corr_skip_table():
+    """Duplicate-row table of the most recent feature_match_index_batched call: int32 [B, x_tiles, 2] = (from, to), ref
+    rows [from, to) of that (sample, x-tile) were not swept (c2m_feature_match_skip_table).  Diagnostics / bench only."""
+    import ctypes
+    if _last_corr is None:
+        raise _lib.C2MError("no correlation has run yet")
+    ws, shp = _last_corr
+    off, nxt = ctypes.c_size_t(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().c2m_feature_match_skip_table(*shp, ctypes.byref(off), ctypes.byref(nxt)),
+               "c2m_feature_match_skip_table")
+    B = shp[0]
+    return ws[off.value:off.value + 8 * B * nxt.value].view(torch.int32).view(B, nxt.value, 2).clone()
 
 
 def build_pre_offsets(max_idx, h, w, scales=(1, 2, 4)):

@@ -198,7 +198,7 @@ template <int C, bool DMA16>
 __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const float* __restrict__ fin, const float* __restrict__ fref, int Hq, int Wq, int Hr, int Wr, int tiles_y,
     int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int is_norm, int norm_input,
-    int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
+    const int2* __restrict__ skip, int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
   using namespace corr;
   constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -252,8 +252,16 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
   const int qx = min(2 * w + hi, TPQ - 1);
   const int lane_off = qx * WT + j32;   // float offset of H[(row 0, qx)][j32] inside a slab
 
+  // Duplicate-row elimination.  skip[b][xt] = (from, to): inside x-tile xt the ref pixel rows [from - 3, to) are bitwise
+  // identical over every channel and every column the tile loads (ref_row_run_kernel below), so the patch rows
+  // from-2 .. to-3 are exact copies of patch row from-3: same scores, same inverse norms, higher index -- they can never
+  // win the (larger value, then LOWER index) rule.  The sweep therefore jumps from row from-1 to row `to`; the ring still
+  // holds the row sums of rows from-2, from-1, which are the row sums of rows to-2, to-1.  (from == to: nothing skipped.)
   const int nxt = (Wrp + WP - 1) / WP;
-  const int S = nxt * Hr;
+  const int2* __restrict__ skb = skip + (size_t)b * nxt;
+  int S = 0;
+  for (int i = 0; i < nxt; ++i) S += Hr - (skb[i].y - skb[i].x);
+  int2 sk = skb[0];
 
   // DMA of ref pixel row (xt, y) into rbuf[buf] = [C][32]: wave w copies channels [C/8 * w, C/8 * (w+1))
   auto issue_row = [&](int xt, int y, int buf) {
@@ -291,7 +299,8 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
 
     // next row's DMA into the other buffer (its last readers were the MFMAs of step s-1)
     int yn = y + 1, xtn = xt;
-    if (yn == Hr) { yn = 0; xtn = xt + 1; }
+    if (yn == sk.x) yn = sk.y;
+    if (yn >= Hr) { yn = 0; xtn = xt + 1; }
     if (s + 1 < S) issue_row(xtn, yn, (s + 1) & 1);
 
     // candidate handled by the NEXT iteration: the patch row completed by THIS step (row y of x-tile xt).  Its inverse
@@ -387,6 +396,7 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       for (int r = 0; r < TPQ; ++r) dst[r * WT] = hh[r];
     }
 
+    if (xtn != xt) sk = skb[min(xtn, nxt - 1)];
     y = yn;
     xt = xtn;
     sl0 = sl1;
@@ -413,6 +423,45 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
       max_val[o] = v;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Duplicate ref rows (see corr_argmax_mfma_kernel).  A zero-padded Ref (ref_cufed_dataset.py:99-114 pads every test Ref
+// to the HR size) leaves a band of identical feature rows; the reference scores every one of them and its strict '>'
+// keeps the first.  ref_row_equal_kernel: eq[b][xt][y] = rows y and y+1 agree bitwise over all channels inside the
+// pixel columns x-tile xt loads.  ref_row_run_kernel: the longest run per (sample, x-tile) -> (from, to).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ref_row_equal_kernel(const float* __restrict__ fref, int C, int Hr, int Wr,
+                                                             int nxt, int* __restrict__ eq) {
+  const int y = blockIdx.x, xt = blockIdx.y, b = blockIdx.z;
+  const int x0 = xt * corr::WP, ncol = min(corr::WT, Wr - x0);
+  const uint32_t* r0 = reinterpret_cast<const uint32_t*>(fref) + (size_t)b * C * Hr * Wr + (size_t)y * Wr + x0;
+  int ok = 1;
+  for (int e = threadIdx.x; e < C * corr::WT; e += 256) {
+    const int c = e / corr::WT, j = e - c * corr::WT;
+    if (j < ncol) {
+      const uint32_t* q = r0 + (size_t)c * Hr * Wr + j;
+      ok &= (q[0] == q[Wr]) ? 1 : 0;
+    }
+  }
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0) eq[((size_t)b * nxt + xt) * Hr + y] = ok;
+}
+
+__global__ void ref_row_run_kernel(const int* __restrict__ eq, int Hr, int n, int2* __restrict__ skip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (sample, x-tile)
+  if (i >= n) return;
+  const int* e = eq + (size_t)i * Hr;
+  int best0 = 0, best1 = 0, start = 0;  // rows [best0, best1] identical
+  for (int y = 0; y < Hr; ++y) {
+    const bool cont = (y < Hr - 1) && e[y];
+    if (!cont) {
+      if (y - start > best1 - best0) { best0 = start; best1 = y; }
+      start = y + 1;
+    }
+  }
+  // rows best0 .. best1 identical: patch rows best0+1 .. best1-2 duplicate patch row best0
+  skip[i] = (best1 - best0 >= 3) ? make_int2(best0 + 3, best1 + 1) : make_int2(Hr, Hr);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -459,7 +508,8 @@ extern "C" int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, in
 
 namespace {
 struct CorrWs {
-  size_t ss_ref, inv, ss_in, qden, total;  // byte offsets
+  size_t ss_ref, inv, ss_in, qden, row_eq, skip, total;  // byte offsets
+  int nxt;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
@@ -469,13 +519,17 @@ inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
   w.inv = o;    o = align256(o + sizeof(float) * (size_t)B * Hr * Wr);
   w.ss_in = o;  o = align256(o + sizeof(float) * (size_t)B * Hq * Wq);
   w.qden = o;   o = align256(o + sizeof(float) * (size_t)B * Hq * Wq);
+  w.nxt = Wr > 2 ? (Wr - 2 + c2m::corr::WP - 1) / c2m::corr::WP : 1;
+  w.row_eq = o; o = align256(o + sizeof(int) * (size_t)B * w.nxt * Hr);
+  w.skip = o;   o = align256(o + sizeof(int2) * (size_t)B * w.nxt);
   w.total = o;
   return w;
 }
 
 template <int C>
 int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B, int Hq, int Wq, int Hr, int Wr,
-                     const float* inv, const float* qden, int64_t* max_idx, float* max_val) {
+                     const float* inv, const float* qden, int* row_eq, int2* skip, int dedup, int64_t* max_idx,
+                     float* max_val) {
   using namespace c2m::corr;
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB + 2 * C * WT);
@@ -484,9 +538,16 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
   auto kern = dma16 ? &corr_argmax_mfma_kernel<C, true> : &corr_argmax_mfma_kernel<C, false>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set[dma16])) return rc;
   dim3 grid(B * tiles_y * tiles_x);
+  const int nxt = ceil_div(Wr - 2, WP);
+  if (dedup) {
+    hipLaunchKernelGGL(ref_row_equal_kernel, dim3(Hr - 1, nxt, B), dim3(256), 0, st, fref, C, Hr, Wr, nxt, row_eq);
+  } else {
+    (void)hipMemsetAsync(row_eq, 0, sizeof(int) * (size_t)B * nxt * Hr, st);
+  }
+  hipLaunchKernelGGL(ref_row_run_kernel, dim3(ceil_div(B * nxt, 64)), dim3(64), 0, st, row_eq, Hr, B * nxt, skip);
   ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y, tiles_x, inv ? inv : fin,
-                     qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, max_idx, max_val);
+                     qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, skip, max_idx, max_val);
   return check_launch();
 }
 }  // namespace
@@ -494,6 +555,14 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
 extern "C" size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr) {
   if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0) return 0;
   return corr_ws(B, Hq, Wq, Hr, Wr).total;
+}
+
+extern "C" int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* byte_offset, int* x_tiles) {
+  if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0 || !byte_offset || !x_tiles) return C2M_ERR_INVALID_ARG;
+  const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr);
+  *byte_offset = ws.skip;
+  *x_tiles = ws.nxt;
+  return C2M_OK;
 }
 
 extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* feat_in, const float* feat_ref, int B,
@@ -536,9 +605,20 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
   const bool fast = !force_generic && patch == 3 && in_stride == 1 && ref_stride == 1 &&
                     (C == 64 || C == 128 || C == 256);
   if (fast) {
-    if (C == 256) return launch_corr_mfma<256>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
-    if (C == 128) return launch_corr_mfma<128>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
-    return launch_corr_mfma<64>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, max_idx, max_val);
+    int* row_eq = reinterpret_cast<int*>(wsb + ws.row_eq);
+    int2* skip = reinterpret_cast<int2*>(wsb + ws.skip);
+    static const int dedup = [] {
+      const char* e = getenv("C2M_CORR_DEDUP");  // 0: score every ref row (measurement / debugging)
+      return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (C == 256)
+      return launch_corr_mfma<256>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
+                                   max_val);
+    if (C == 128)
+      return launch_corr_mfma<128>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
+                                   max_val);
+    return launch_corr_mfma<64>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
+                                max_val);
   }
   const size_t lds = sizeof(float) * (size_t)patch * patch * C;
   if (lds > 60 * 1024) return C2M_ERR_UNSUPPORTED;

@@ -67,8 +67,16 @@ int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
 /* x, out: [B][C][HW] fp32.  out[b,c,p] = x[b,c,p] / max(||x[b,:,p]||_2, 1e-12).  In-place allowed. */
 int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out);
 
-/* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps). */
+/* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps, duplicate-row table). */
 size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr);
+
+/*
+ * Diagnostics for the MFMA kernel's duplicate-row elimination: after c2m_feature_match_index_f32 the workspace holds,
+ * at *byte_offset, int32 pairs [B][*x_tiles][2] = (from, to): ref pixel rows [from, to) of that (sample, x-tile) were
+ * not swept because they repeat rows from-3 .. from-1 bit for bit (their patch rows can never win the lowest-index
+ * tie rule of ref_map_util.py:74).  from == to: every row swept.  $C2M_CORR_DEDUP=0 disables the elimination.
+ */
+int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* byte_offset, int* x_tiles);
 
 /*
  * feat_in [B][C][Hq][Wq], feat_ref [B][C][Hr][Wr] fp32 contiguous; for every sample b independently

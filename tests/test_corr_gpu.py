@@ -100,6 +100,58 @@ def test_exact_ties_across_x_tiles_and_rows(env, dev):
         assert int(oi.max()) < 10 * (wr - 2)   # ties resolved into the first vertical period
 
 
+def _band_ref(oracle, synth, C, hr, seed, bands):
+    """ref map with runs of bitwise-identical pixel rows: bands = [(first_row, last_row, x_from)], the run only holding
+    for pixel columns >= x_from (0 = whole rows)."""
+    fr = oracle.feature_normalize(synth.gaussish((C,) + hr, seed))
+    for r0, r1, x0 in bands:
+        fr[:, r0:r1 + 1, x0:] = fr[:, r0:r0 + 1, x0:]
+    return np.ascontiguousarray(fr)
+
+
+@pytest.mark.parametrize("hr,bands,expect", [
+    ((40, 70), [(9, 20, 0)], {0: (12, 21), 1: (12, 21), 2: (12, 21)}),          # a run in the middle, every x-tile
+    ((40, 70), [(0, 6, 0), (30, 39, 0)], {0: (33, 40)}),                         # two runs: the longer (bottom) one wins
+    ((40, 70), [(0, 39, 56)], {0: (40, 40), 1: (40, 40), 2: (3, 40)}),           # constant columns: only x-tile 2 skips
+    ((40, 70), [(5, 7, 0)], {0: (40, 40)}),                                      # 3 equal rows = 1 patch row: nothing to skip
+    ((24, 33), [(4, 12, 0), (14, 23, 0)], {0: (17, 24), 1: (17, 24)}),
+])
+def test_duplicate_row_elimination_is_exact(env, dev, hr, bands, expect):
+    """The MFMA kernel does not sweep ref rows that repeat the three rows before them (zero-padded Refs): index map and
+    values must still equal the oracle's, which scores every candidate, and the skip table must be the expected one."""
+    ops, oracle, synth = env
+    C = 64
+    fi = oracle.feature_normalize(synth.gaussish((C, 21, 19), 7))
+    fr = _band_ref(oracle, synth, C, hr, 8, bands)
+    # some queries ARE patches of the repeated band, so the duplicates are exact ties for the maximum
+    fi[:, 2:5, 3:6] = fr[:, bands[0][0]:bands[0][0] + 3, hr[1] - 4:hr[1] - 1]
+    idx, val, tab = ops.feature_match_index_batched(_t(fi[None], dev), _t(fr[None], dev), return_skip=True)
+    oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, False)
+    assert np.array_equal(idx[0].cpu().numpy(), oi)
+    assert np.array_equal(val[0].cpu().numpy(), ov)
+    tab = tab[0].cpu().numpy()
+    for xt, (a, b) in expect.items():
+        assert tuple(tab[xt]) == (a, b), (xt, tab)
+    gi, gv = ops.feature_match_index_batched(_t(fi[None], dev), _t(fr[None], dev), force_generic=True)
+    assert np.array_equal(gi[0].cpu().numpy(), oi) and np.array_equal(gv[0].cpu().numpy(), ov)
+
+
+def test_duplicate_rows_differ_per_sample(env, dev):
+    ops, oracle, synth = env
+    C = 128
+    fi = np.stack([oracle.feature_normalize(synth.gaussish((C, 18, 18), 20 + b)) for b in range(3)])
+    fr = np.stack([_band_ref(oracle, synth, C, (36, 36), 30, [(20, 35, 0)]),
+                   _band_ref(oracle, synth, C, (36, 36), 31, []),
+                   _band_ref(oracle, synth, C, (36, 36), 32, [(2, 30, 0)])])
+    idx, val, tab = ops.feature_match_index_batched(_t(fi, dev), _t(fr, dev), return_skip=True)
+    tab = tab.cpu().numpy()
+    assert tab[0].tolist() == [[23, 36], [23, 36]] and tab[1].tolist() == [[36, 36], [36, 36]]
+    assert tab[2].tolist() == [[5, 31], [5, 31]]
+    for b in range(3):
+        oi, ov = oracle.feature_match_index(fi[b], fr[b], 3, 1, 1, True, False)
+        assert np.array_equal(idx[b].cpu().numpy(), oi) and np.array_equal(val[b].cpu().numpy(), ov)
+
+
 def test_midsize_80(env, dev):
     ops, oracle, synth = env
     fi = oracle.feature_normalize(synth.gaussish((256, 80, 80), 81))
