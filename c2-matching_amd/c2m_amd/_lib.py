@@ -28,7 +28,9 @@ class Conv3x3Desc(ctypes.Structure):
                 ("wr", _vp), ("bias", _vp), ("act", _i), ("slope", ctypes.c_float), ("out_mode", _i), ("out", _vp),
                 ("out_pix_pitch", _i), ("out_row_pitch", _i), ("out_img_pitch", ctypes.c_longlong), ("res1", _vp),
                 ("res2", _vp), ("mask_out", _vp), ("flow", _vp), ("fh", _i), ("fw", _i), ("scale", _i), ("n_off", _i),
-                ("abs_sum", _vp), ("algo", _i), ("cout_offset", _i), ("cout_total", _i)]
+                ("abs_sum", _vp), ("algo", _i), ("cout_offset", _i), ("cout_total", _i),
+                ("out2", _vp), ("out2_row_pitch", _i), ("out2_plane_pitch", ctypes.c_longlong),
+                ("out2_img_pitch", ctypes.c_longlong)]
 
 
 class C2MError(RuntimeError):
@@ -62,7 +64,7 @@ def _declare(L):
     L.c2m_dcn_v2_relayout_bytes.restype = _sz
     L.c2m_dcn_v2_relayout_bytes.argtypes = [_i] * 5
     L.c2m_dcn_v2_relayout_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp]
-    L.c2m_dcn_v2_forward_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_float]
+    L.c2m_dcn_v2_forward_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_float, _i]
     L.c2m_conv3x3_relayout_bytes.restype = _sz
     L.c2m_conv3x3_relayout_bytes.argtypes = [_i, _i]
     L.c2m_conv3x3_relayout_f32.argtypes = [_vp, _vp, _i, _i, _vp]

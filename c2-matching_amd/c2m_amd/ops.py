@@ -262,18 +262,25 @@ def _wino_ok(srcs, weight, out_mode, W):
             all(s.shape[1] % 16 == 0 for s in srcs) and sum(s.shape[1] for s in srcs) == weight.shape[1])
 
 
-def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None):
+def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,
+            out2_grouped8=None):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
 
     srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
     the (zero-padded) weight is not accepted -- pad the tensor).  out_mode: "nhwc" -> channels_last [B,Cout,H,W];
-    "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous."""
+    "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous.
+    out2_grouped8: a zero-bordered group-major buffer [B,Cout/8,H+3,W+3,8] that receives a second copy of the output
+    (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only."""
     srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
     B, _, H, W = srcs[0].shape
     Cin = sum(s.shape[1] for s in srcs)
     Cout = weight.shape[0]
     dev = srcs[0].device
     wino = _wino_ok(srcs, weight, out_mode, W) if algo is None else (algo == "winograd")
+    if out2_grouped8 is not None:
+        if algo == "winograd" or out_mode != "nhwc":
+            raise _lib.C2MError("out2_grouped8 needs the direct kernel in nhwc mode")
+        wino = False
     wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None, wino=wino)
     d = _lib.Conv3x3Desc()
     d.algo = 1 if wino else 0
@@ -299,6 +306,15 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
                 if (rs.pix_pitch, rs.row_pitch, rs.img_pitch) != (o.pix_pitch, o.row_pitch, o.img_pitch) or r.shape != out.shape:
                     raise _lib.C2MError(f"{name} must have the geometry of the output")
                 setattr(d, name, r.data_ptr())
+        if out2_grouped8 is not None:
+            g2 = out2_grouped8
+            if (g2.dtype != torch.float32 or not g2.is_contiguous() or Cout % 8 != 0 or
+                    tuple(g2.shape) != (B, Cout // 8, H + 3, W + 3, 8) or g2.device != dev):
+                raise _lib.C2MError("out2_grouped8 must be a contiguous float32 [B, Cout/8, H+3, W+3, 8] buffer")
+            d.out2 = g2.data_ptr() + ((W + 3) + 1) * 8 * 4          # image pixel (0, 0) = bordered pixel (1, 1)
+            d.out2_row_pitch = (W + 3) * 8
+            d.out2_plane_pitch = (H + 3) * (W + 3) * 8
+            d.out2_img_pitch = (Cout // 8) * (H + 3) * (W + 3) * 8
     elif out_mode == "pixel_shuffle":
         out = empty_nhwc(B, Cout // 4, 2 * H, 2 * W, dev)
         d.out_mode = 1
@@ -385,7 +401,10 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
 # channels-last output with the activation folded in
 # ---------------------------------------------------------------------------------------------------------------------
 class BorderedNHWC:
-    """Zero-bordered channels-last copy [B][H+3][W+3][C] of an NCHW feature map (what the DCNv2 kernels gather from)."""
+    """Zero-bordered channels-last copy [B][H+3][W+3][C] of an NCHW feature map (what the DCNv2 kernels gather from).
+    `grouped8`: optional twin in the 8-channel group-major layout [B][C/8][H+3][W+3][8], written by the producing
+    convolution's epilogue; DCNv2 layers with 8 channels per deformable group gather from it instead."""
+    grouped8 = None
 
     def __new__(cls, x=None):
         pre = bordered_of(x) if x is not None else None   # already the interior view of a bordered buffer: no copy
@@ -449,10 +468,13 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     else:
         out = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
         pitches = (0, 0, 0, 0)
+    grouped = inp_bordered.grouped8 is not None and C == 8 * dg
+    src = inp_bordered.grouped8 if grouped else inp_bordered.buf
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f32(_stream(), inp_bordered.buf.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+        _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f32(_stream(), src.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                                                          offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1, 1,
-                                                         1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope)),
+                                                         1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope),
+                                                         int(grouped)),
                    "c2m_dcn_v2_forward_nhwc_f32")
     return out
 
@@ -460,8 +482,9 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
 # ---------------------------------------------------------------------------------------------------------------------
 # VGG-style feature stacks (conv3x3 + ReLU + 2x2 max-pool) on the channels-last kernels
 # ---------------------------------------------------------------------------------------------------------------------
-def _bordered_empty(B, C, H, W, device):
-    """BorderedNHWC whose border is zero and whose interior is uninitialised (to be written by a conv epilogue)."""
+def _bordered_empty(B, C, H, W, device, grouped8=False):
+    """BorderedNHWC whose border is zero and whose interior is uninitialised (to be written by a conv epilogue).
+    grouped8: also allocate the group-major twin (same border)."""
     o = BorderedNHWC.__new__(BorderedNHWC)
     o.B, o.C, o.H, o.W = B, C, H, W
     o.buf = torch.empty((B, H + 3, W + 3, C), dtype=torch.float32, device=device)
@@ -469,6 +492,15 @@ def _bordered_empty(B, C, H, W, device):
     o.buf[:, H + 1:].zero_()
     o.buf[:, 1:H + 1, 0].zero_()
     o.buf[:, 1:H + 1, W + 1:].zero_()
+    if grouped8:
+        if C % 8 != 0:
+            raise _lib.C2MError("a group-major twin needs C % 8 == 0")
+        g = torch.empty((B, C // 8, H + 3, W + 3, 8), dtype=torch.float32, device=device)
+        g[:, :, 0].zero_()
+        g[:, :, H + 1:].zero_()
+        g[:, :, 1:H + 1, 0].zero_()
+        g[:, :, 1:H + 1, W + 1:].zero_()
+        o.grouped8 = g
     return o
 
 
@@ -477,14 +509,15 @@ def bordered_of(t):
     return getattr(t, "_c2m_bordered", None)
 
 
-def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False):
+def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, grouped8_taps=()):
     """Run an ordered {name: nn.Conv2d(3x3, pad 1) | nn.ReLU | nn.MaxPool2d(2, 2)} stack (torchvision's vgg `features`
     layout, mmsr/models/archs/vgg_arch.py:107-123) on the fused channels-last convolution: every conv + its ReLU is one
     launch.  x: [B,3,H,W] image; (x - mean) / std is applied while the image is widened to the kernel's 32-channel chunk.
     Returns {tap name: tensor}; tapped activations are written by the conv epilogue straight into zero-bordered
     channels-last buffers (logical NCHW views of their interiors are returned: the DCNv2 gathers and the offset
     convolutions of the decoder read those buffers in place).  last_nchw: the final layer's output as a contiguous NCHW
-    tensor under the key of that layer (the correlation kernels read planar features)."""
+    tensor under the key of that layer (the correlation kernels read planar features).  grouped8_taps: taps that also get
+    the group-major twin (BorderedNHWC.grouped8) a DCNv2 layer with 8-channel deformable groups gathers from."""
     names = list(layers.keys())
     B, C, H, W = x.shape
     dev = x.device
@@ -509,9 +542,10 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False):
                 cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out_mode="nchw")
                 out[names[k + 1] if relu else name] = cur
             elif tap_name is not None:
-                bo = _bordered_empty(Bc, layer.out_channels, Hc, Wc, dev)
+                bo = _bordered_empty(Bc, layer.out_channels, Hc, Wc, dev, grouped8=tap_name in grouped8_taps)
                 view = bo.interior()
-                conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out=view)
+                conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out=view,
+                        out2_grouped8=bo.grouped8)
                 view._c2m_bordered = bo
                 out[tap_name] = view
                 cur = view

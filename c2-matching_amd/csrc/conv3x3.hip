@@ -80,6 +80,9 @@ struct Params {
   int out_vec4;          // mode 0: out / res pitches and bases are 16-byte aligned -> float4 stores
   int tpw;               // consecutive tiles per workgroup (>= 1)
   int co_off, cout_total;// mode 3: this launch computes head channels [co_off, co_off + Cout) of cout_total
+  float* out2;           // mode 0 (direct kernel, float4 stores): second copy of the output, 8-channel group-major
+  int out2_row_pitch;    //   out2[b*img + (co/8)*plane + y*row + x*8 + co%8]: the layout the DCNv2 kernel gathers 8-channel
+  long long out2_plane_pitch, out2_img_pitch;   // groups from (c2m_dcn_v2_forward_nhwc_f32, input_grouped)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -468,6 +471,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
                 if (co + 3 < p.Cout) {
                   v += res4[mt][qd];
                   *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+                  if (p.out2)
+                    *reinterpret_cast<f32x4*>(p.out2 + (size_t)b * p.out2_img_pitch + (size_t)(co >> 3) * p.out2_plane_pitch +
+                                              (size_t)y * p.out2_row_pitch + x * 8 + (co & 7)) = v;
                 } else {
                   for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
                     float sv = v[e];
@@ -942,6 +948,11 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.out_vec4 = out_vec4 ? 1 : 0;
   p.co_off = d->out_mode == 3 ? d->cout_offset : 0;
   p.cout_total = cout_total;
+  p.out2 = d->out2; p.out2_row_pitch = d->out2_row_pitch; p.out2_plane_pitch = d->out2_plane_pitch;
+  p.out2_img_pitch = d->out2_img_pitch;
+  if (d->out2 && (wino || d->out_mode != 0 || !out_vec4 || d->Cout % 8 != 0 || ((uintptr_t)d->out2 & 15) ||
+                  d->out2_row_pitch % 4 != 0 || d->out2_plane_pitch % 4 != 0 || d->out2_img_pitch % 4 != 0))
+    return C2M_ERR_UNSUPPORTED;
 
   const int MW = wino ? 64 : conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;

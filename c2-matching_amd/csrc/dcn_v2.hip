@@ -41,6 +41,11 @@ struct Geom {
   int out_nhwc, out_pix_pitch, out_row_pitch, act;
   long long out_img_pitch;
   float slope;
+  // layout of the zero-bordered staging copy the channels-last kernel gathers from: 0 = [H+3][W+3][C]; 1 = group-major
+  // [dg][H+3][W+3][C/dg] (real groups).  With 8-channel groups a sample is a 32-byte run: channels-last puts every
+  // (pixel, group, corner) on its own 128-byte line, group-major puts the two horizontal corners and the neighbouring
+  // pixels' samples of a coherent flow on shared lines (large layer, B=16: 7.6 -> 5.9 ms).
+  int in_grouped;
 };
 
 // bilinear sampling state of one (pixel, group, tap)
@@ -314,6 +319,25 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc64_kernel(const float* __rest
   }
 }
 
+// Group-major variant of the bordered copy: out[b][c / G][(H+3)*(W+3)][G] (Geom::in_grouped).  One thread per (group, bordered
+// pixel): G plane reads (coalesced across the wave), one contiguous G-element record written.
+template <typename OutT, int G>
+__global__ void __launch_bounds__(256) nchw_to_grouped_kernel(const float* __restrict__ in, int C, int H, int W,
+                                                               OutT* __restrict__ out) {
+  const int Wp = W + 3, PP = (H + 3) * Wp, HW = H * W;
+  const int pp = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y, b = blockIdx.z;
+  if (pp >= PP) return;
+  const int yy = pp / Wp - 1, xx = pp - (yy + 1) * Wp - 1;
+  const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+  const float* ib = in + ((size_t)b * C + (size_t)grp * G) * HW + (inside ? yy * W + xx : 0);
+  OutT v[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) v[c] = (OutT)(inside ? ib[(size_t)c * HW] : 0.0f);
+  OutT* o = out + (((size_t)b * (C / G) + grp) * PP + pp) * G;
+#pragma unroll
+  for (int c = 0; c < G; ++c) o[c] = v[c];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward, channels-last gathers + LDS-staged weights.  Wave tiling as dcn_fwd_mfma_kernel, K order (tap, group, kk).
 //   * lane (hi, j) owns the contiguous half-run of CPG/2 channels [hi*CPG/2, (hi+1)*CPG/2) of its group: one float4
@@ -354,6 +378,15 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
   const int dg_real = SPLITG ? 2 * g.dg : g.dg;
   const float* off_b = offset + (size_t)b * dg_real * 2 * g.T * HWo;
   const float* msk_b = mask + (size_t)b * dg_real * g.T * HWo;
+  // Everything this sample reads goes through three buffer resources (32-bit byte offsets: a per-lane VGPR part, a
+  // wave-uniform SGPR part and an instruction immediate) -- no 64-bit address arithmetic on the vector ALU, which this
+  // kernel is bound by.  use_nhwc() keeps each of the three ranges below 2 GiB.
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(in_b), 0, (int)((unsigned)g.C * (unsigned)(g.H + 3) * (unsigned)Wp * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t off_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(off_b), 0, (int)((unsigned)dg_real * 2u * (unsigned)g.T * (unsigned)HWo * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t msk_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(msk_b), 0, (int)((unsigned)dg_real * (unsigned)g.T * (unsigned)HWo * 4u), 0x00020000);
 
   int pc[NT];
   float fy[NT], fx[NT];   // sample position of tap (0, 0) without offset
@@ -405,9 +438,23 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
   //   raw offsets/mask of step gs+2 are loaded, the sampling state + gathers of step gs+1 are issued, then the
   //   bilinear blend + MFMAs of step gs run on data requested one step earlier.
   const int nstep = g.T * g.dg;
-  auto raw_at = [&](int tap, int grp, RawTap (&r)[NT]) {
+  // raw offsets / mask of (tap, group): plane gt = group*T + tap of this sample, element pc.  With SPLITG half-wave hi
+  // reads real group 2*grp + hi: that part of the address is per-lane but constant, so it lives in the VGPR offset.
+  int rv_off[NT], rv_msk[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) r[nt] = load_raw_tap(g, off_b, msk_b, SPLITG ? 2 * grp + hi : grp, tap, pc[nt]);
+  for (int nt = 0; nt < NT; ++nt) {
+    rv_off[nt] = (pc[nt] + (SPLITG ? hi * 2 * g.T * HWo : 0)) * 4;
+    rv_msk[nt] = (pc[nt] + (SPLITG ? hi * g.T * HWo : 0)) * 4;
+  }
+  auto raw_at = [&](int tap, int grp, RawTap (&r)[NT]) {
+    const int gt = (SPLITG ? 2 * grp : grp) * g.T + tap;   // wave-uniform
+    const int so = 2 * gt * HWo * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      r[nt].oh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rs, rv_off[nt], so, 0));
+      r[nt].ow = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rs, rv_off[nt], so + HWo * 4, 0));
+      r[nt].mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msk_rs, rv_msk[nt], gt * HWo * 4, 0));
+    }
   };
   struct Gath { f32x4 v1[NQ], v2[NQ], v3[NQ], v4[NQ]; };
   // Sampling state of one (pixel, group, tap): element offset of the top-left corner in the bordered copy and the four
@@ -416,27 +463,32 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
   struct Samp { unsigned o1; float w1, w2, w3, w4; };
   struct Wts { float w1, w2, w3, w4; };
   const float Hf = (float)g.H, Wf = (float)g.W;
-  const unsigned lane_ch = hi * HALF;   // this lane's half-run inside its group
-  const int obase = (Wp + 1) * g.C + (int)lane_ch;   // bordered pixel (1, 1) = image pixel (0, 0)
+  constexpr int CPGR = SPLITG ? CPG / 2 : CPG;         // channels of a real group
+  const int plane = (g.H + 3) * Wp * CPGR * ES;        // group-major: bytes of one group's plane
+  const int cpix = (g.in_grouped ? CPGR : g.C) * ES, crow = Wp * cpix;   // bytes to the right / lower corner
+  // per-lane constant part of a gather offset: bordered pixel (1, 1) = image pixel (0, 0), plus this lane's half-run
+  // (channels-last: inside the pixel's C channels; group-major: inside its real group's plane)
+  const int lane_o = (Wp + 1) * cpix + (g.in_grouped ? (SPLITG ? hi * plane : hi * HALF * ES) : hi * HALF * ES);
   auto gather = [&](int grp, const Samp (&sp)[NT], Gath (&gv)[NT]) {
-    const char* gb = in_b + grp * CPG * ES;   // wave-uniform base; per-lane part stays a 32-bit element offset
+    // the four corners share the lane's byte offset sp.o1; group and corner displacement are wave-uniform (SGPR offset)
+    const int s1 = g.in_grouped ? (SPLITG ? 2 * grp : grp) * plane : grp * CPG * ES, s2 = s1 + cpix, s3 = s1 + crow,
+              s4 = s3 + cpix;
+    auto ld = [&](int voff, int so, int imm) __attribute__((always_inline)) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, voff + imm, so, 0));
+    };
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const unsigned o1 = sp[nt].o1, o2 = o1 + (unsigned)g.C, o3 = o1 + (unsigned)(Wp * g.C), o4 = o3 + (unsigned)g.C;
-      // corner-major issue order, one base pointer + immediate offsets per corner: the 16-byte pieces of one corner's
-      // channel run share a cache line and should reach the texture path back to back (random flows: 15 % slower otherwise)
-      const f32x4* c1 = reinterpret_cast<const f32x4*>(gb + (size_t)o1 * ES);
-      const f32x4* c2 = reinterpret_cast<const f32x4*>(gb + (size_t)o2 * ES);
-      const f32x4* c3 = reinterpret_cast<const f32x4*>(gb + (size_t)o3 * ES);
-      const f32x4* c4 = reinterpret_cast<const f32x4*>(gb + (size_t)o4 * ES);
+      const int o1 = (int)sp[nt].o1;
+      // corner-major issue order: the 16-byte pieces of one corner's channel run share a cache line and should reach the
+      // texture path back to back (random flows: 15 % slower otherwise)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) gv[nt].v1[q] = c1[q];
+      for (int q = 0; q < NQ; ++q) gv[nt].v1[q] = ld(o1, s1, q * 16);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) gv[nt].v2[q] = c2[q];
+      for (int q = 0; q < NQ; ++q) gv[nt].v2[q] = ld(o1, s2, q * 16);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) gv[nt].v3[q] = c3[q];
+      for (int q = 0; q < NQ; ++q) gv[nt].v3[q] = ld(o1, s3, q * 16);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) gv[nt].v4[q] = c4[q];
+      for (int q = 0; q < NQ; ++q) gv[nt].v4[q] = ld(o1, s4, q * 16);
     }
   };
 
@@ -468,7 +520,7 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
       const float hw = 1.0f - lw;
       const float mh = (1.0f - lh) * r[nt].mk, ml = lh * r[nt].mk;
       sp[nt].w1 = mh * hw; sp[nt].w2 = mh * lw; sp[nt].w3 = ml * hw; sp[nt].w4 = ml * lw;
-      sp[nt].o1 = (unsigned)(((int)fh * Wp + (int)fw) * g.C + obase);
+      sp[nt].o1 = (unsigned)(((int)fh * Wp + (int)fw) * cpix + lane_o);
     }
   };
   // One pipeline step: issue (state + gathers) of step gs+1 into (wB, gvB) and the raw loads of step gs+2, then blend +
@@ -534,23 +586,44 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_k
     } else {
     // MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
     const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
-    float aop[2][MT], col[2][NT];
+    // The blend runs on channel PAIRS (v_pk_mul_f32 / v_pk_fma_f32: two fp32 lanes per instruction, 4 instructions per
+    // pair instead of 8): pair u = channels (2u, 2u+1) of the lane's half-run, i.e. the B operands of k-pairs 2u, 2u+1.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto blend2 = [&](int u, f32x2 (&c)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) aop[0][mt] = wrow[mt * 32];
-    blend(0, col[0]);
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 q1 = gvA[nt].v1[u >> 1], q2 = gvA[nt].v2[u >> 1], q3 = gvA[nt].v3[u >> 1], q4 = gvA[nt].v4[u >> 1];
+        const int e = (u & 1) * 2;
+        const f32x2 a1 = {q1[e], q1[e + 1]}, a2 = {q2[e], q2[e + 1]}, a3 = {q3[e], q3[e + 1]}, a4 = {q4[e], q4[e + 1]};
+        const f32x2 k1 = {wA[nt].w1, wA[nt].w1}, k2 = {wA[nt].w2, wA[nt].w2}, k3 = {wA[nt].w3, wA[nt].w3},
+                    k4 = {wA[nt].w4, wA[nt].w4};
+        c[nt] = __builtin_elementwise_fma(k4, a4, __builtin_elementwise_fma(k3, a3, __builtin_elementwise_fma(k2, a2, k1 * a1)));
+      }
+    };
+    static_assert(HALF % 2 == 0, "channel pairs");
+    float aop[2][2][MT];
+    f32x2 col[2][NT];
 #pragma unroll
-    for (int t = 0; t < HALF; ++t) {
-      if (t + 1 < HALF) {
+    for (int mt = 0; mt < MT; ++mt) { aop[0][0][mt] = wrow[mt * 32]; aop[0][1][mt] = wrow[2 * MW + mt * 32]; }
+    blend2(0, col[0]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) aop[(t + 1) & 1][mt] = wrow[(2 * (t + 1)) * MW + mt * 32];
-        blend(t + 1, col[(t + 1) & 1]);
+    for (int u = 0; u < HALF / 2; ++u) {
+      if (u + 1 < HALF / 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          aop[(u + 1) & 1][0][mt] = wrow[(2 * (2 * u + 2)) * MW + mt * 32];
+          aop[(u + 1) & 1][1][mt] = wrow[(2 * (2 * u + 3)) * MW + mt * 32];
+        }
+        blend2(u + 1, col[(u + 1) & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[t & 1][mt], col[t & 1][nt], acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[u & 1][h][mt], col[u & 1][nt][h], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     }
@@ -1163,6 +1236,7 @@ int make_geom(Geom& g, int B, int C, int H, int W, int Co, int kh, int kw, int s
     return C2M_ERR_INVALID_ARG;
   g.B = B; g.C = C; g.H = H; g.W = W; g.Co = Co; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
   g.dh = dh; g.dw = dw; g.dg = dg;
+  g.in_grouped = 0;
   g.out_nhwc = 0; g.out_pix_pitch = 0; g.out_row_pitch = 0; g.out_img_pitch = 0; g.act = 0; g.slope = 0.0f;
   g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
@@ -1239,7 +1313,12 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
 
 // channels-last fast path: 8/16/32 channels per deformable group and an even number of groups (its step pairs and weight
 // chunks cover two groups at a time); everything else takes the NCHW kernel
-inline bool use_nhwc(const Geom& g) { return (g.CPG == 8 || g.CPG == 16 || g.CPG == 32) && g.dg % 2 == 0; }
+// (and samples whose staged copy or offset planes reach 2 GiB: the kernel addresses them with 32-bit buffer offsets)
+inline bool use_nhwc(const Geom& g) {
+  const unsigned long long lim = 1ull << 31;
+  const unsigned long long copy = 4ull * g.C * (g.H + 3) * (g.W + 3), offs = 4ull * g.dg * 2 * g.T * g.Ho * g.Wo;
+  return (g.CPG == 8 || g.CPG == 16 || g.CPG == 32) && g.dg % 2 == 0 && copy < lim && offs < lim;
+}
 
 template <int MT, int NT>
 void launch_fwd(hipStream_t st, const float* in, const float* wt, const float* bias, const float* off, const float* msk,
@@ -1261,8 +1340,11 @@ extern "C" size_t c2m_dcn_v2_forward_workspace_bytes(int B, int C, int H, int W,
 namespace {
 // zero-bordered channels-last copy of `input` (fp32, or bf16 for the bf16-MFMA forward)
 template <typename OutT>
-void launch_nhwc_copy(hipStream_t st, const float* input, int B, int C, int H, int W, OutT* out) {
-  if (C % 64 == 0)
+void launch_nhwc_copy(hipStream_t st, const float* input, int B, int C, int H, int W, OutT* out, bool grouped8 = false) {
+  if (grouped8)
+    hipLaunchKernelGGL((dcn::nchw_to_grouped_kernel<OutT, 8>), dim3(ceil_div((H + 3) * (W + 3), 256), C / 8, B), dim3(256), 0, st,
+                       input, C, H, W, out);
+  else if (C % 64 == 0)
     hipLaunchKernelGGL(dcn::nchw_to_nhwc64_kernel<OutT>, dim3(ceil_div((H + 3) * (W + 3), 64), C / 64, B), dim3(256), 0, st,
                        input, C, H, W, out);
   else
@@ -1274,6 +1356,7 @@ void launch_nhwc_copy(hipStream_t st, const float* input, int B, int C, int H, i
 // copy (shared with the offset convolutions) and the re-laid-out weights (cached while the weights do not change).
 struct FwdExt {
   const float* inl = nullptr;   // bordered channels-last input [B][H+3][W+3][C]; nullptr: made here from `input`
+  int in_grouped = 0;           // `inl` is group-major [B][dg][H+3][W+3][C/dg] instead (8-channel groups only)
   const float* wt = nullptr;    // weights in the forward kernel's layout; nullptr: re-laid-out here from `weight`
   int out_nhwc = 0, out_pix_pitch = 0, out_row_pitch = 0, act = 0;
   long long out_img_pitch = 0;
@@ -1311,9 +1394,13 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
   if (split) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
   // bf16 MFMA variant: channels-last geometries whose half-run is a multiple of 8 channels; anything else computes in fp32
   const bool bf16 = want_bf16 && nhwc && gk.CPG >= 16;
+  // 8-channel groups gather from a group-major copy (see Geom::in_grouped); a caller-provided copy says which it is
+  if (ext.in_grouped && !(ext.inl && nhwc && g.CPG == 8)) return C2M_ERR_UNSUPPORTED;
+  const bool grouped = ext.inl ? ext.in_grouped != 0 : (nhwc && g.CPG == 8);
+  g.in_grouped = gk.in_grouped = grouped ? 1 : 0;
   if (nhwc && !ext.inl) {
-    if (bf16) launch_nhwc_copy(st, input, B, C, H, W, reinterpret_cast<__bf16*>(inl));
-    else launch_nhwc_copy(st, input, B, C, H, W, inl);
+    if (bf16) launch_nhwc_copy(st, input, B, C, H, W, reinterpret_cast<__bf16*>(inl), grouped);
+    else launch_nhwc_copy(st, input, B, C, H, W, inl, grouped);
   }
   if (!ext.wt) {
     if (bf16)
@@ -1384,9 +1471,9 @@ extern "C" int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* inp
                                            const float* bias, const float* offset, const float* mask, int B, int C, int H,
                                            int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                                            int dg, float* output, int out_nhwc, int out_pix_pitch, int out_row_pitch,
-                                           long long out_img_pitch, int act, float slope) {
+                                           long long out_img_pitch, int act, float slope, int input_grouped) {
   FwdExt ext;
-  ext.inl = input_bordered; ext.wt = wt; ext.out_nhwc = out_nhwc; ext.out_pix_pitch = out_pix_pitch;
+  ext.inl = input_bordered; ext.in_grouped = input_grouped; ext.wt = wt; ext.out_nhwc = out_nhwc; ext.out_pix_pitch = out_pix_pitch;
   ext.out_row_pitch = out_row_pitch; ext.out_img_pitch = out_img_pitch; ext.act = act; ext.slope = slope;
   return dcn_forward(stream, nullptr, nullptr, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
                      nullptr, 0, false, ext);

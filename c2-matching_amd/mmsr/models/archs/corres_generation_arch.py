@@ -77,6 +77,10 @@ class CorrespondenceGenerationArch(nn.Module):
         self.stride = stride
         self.vgg_layer_list = vgg_layer_list
         self.vgg = VGGFeatureExtractor(layer_name_list=vgg_layer_list, vgg_type=vgg_type)
+        # fused inference path only: relu1_1 (64 channels) is what the restoration net's large DynAgg warps with 8
+        # deformable groups (ref_restoration_arch.py:73-76, 176-180), i.e. 8-channel groups -- its producer also writes the
+        # group-major copy that DCNv2 geometry gathers from (ops.BorderedNHWC.grouped8).  Unused by any other consumer.
+        self.vgg.grouped8_taps = ('relu1_1',)
 
     def index_to_flow(self, max_idx):
         """(h, w) int64 index map of ONE sample -> [1, h+2, w+2, 2] flow (x, y), zero-padded bottom/right

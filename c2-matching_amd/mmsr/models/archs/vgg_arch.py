@@ -132,7 +132,8 @@ class VGGFeatureExtractor(nn.Module):
             from c2m_amd import ops as _ops
             return _ops.vgg_stack_forward(self.vgg_net._modules, x, taps=self.layer_name_list,
                                           mean=self.mean if self.use_input_norm else None,
-                                          std=self.std if self.use_input_norm else None)
+                                          std=self.std if self.use_input_norm else None,
+                                          grouped8_taps=getattr(self, 'grouped8_taps', ()))
         if self.use_input_norm:
             x = (x - self.mean) / self.std
         taps = {}

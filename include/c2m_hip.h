@@ -132,7 +132,10 @@ int c2m_dcn_v2_forward_bf16mma_f32(c2m_stream_t stream, const float* input, cons
  *   c2m_dcn_v2_forward_nhwc_f32     dcn_v2_cuda_forward (dcn_v2_cuda.cu:42-172) from those two; output planar
  *                                   [B][Co][Ho][Wo] (out_nhwc = 0) or channels-last with the given pitches (in floats)
  *                                   and an optional fused activation (C2M_ACT_*: the lrelu that follows every DynAgg,
- *                                   ref_restoration_arch.py:152-154).
+ *                                   ref_restoration_arch.py:152-154).  input_grouped = 1 (C / dg == 8 only):
+ *                                   input_bordered is group-major [B][dg][H+3][W+3][8] instead -- a 32-byte sample run
+ *                                   then shares its 128-byte line with the neighbouring positions of the same group
+ *                                   instead of with three other groups (c2m_conv3x3_desc.out2 writes this layout).
  */
 int c2m_nchw_to_nhwc_bordered_f32(c2m_stream_t stream, const float* input, int B, int C, int H, int W, float* out);
 size_t c2m_dcn_v2_relayout_bytes(int C, int Co, int kh, int kw, int dg);
@@ -140,7 +143,8 @@ int c2m_dcn_v2_relayout_f32(c2m_stream_t stream, const float* weight, int C, int
 int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* input_bordered, const float* wt, const float* bias,
                                 const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh, int kw,
                                 int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output, int out_nhwc,
-                                int out_pix_pitch, int out_row_pitch, long long out_img_pitch, int act, float slope);
+                                int out_pix_pitch, int out_row_pitch, long long out_img_pitch, int act, float slope,
+                                int input_grouped);
 
 size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                                            int pw, int dh, int dw, int dg);
@@ -218,6 +222,11 @@ typedef struct c2m_conv3x3_desc {
   int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
   int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
                               head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
+  float* out2;             /* NHWC + C2M_CONV_DIRECT only, or NULL: a second copy of the output in the 8-channel group-major
+                              layout out2[b*img + (co/8)*plane + y*row + x*8 + co%8] (pitches in floats, multiples of 4) --
+                              what c2m_dcn_v2_forward_nhwc_f32(input_grouped = 1) gathers from.  Cout % 8 == 0 */
+  int out2_row_pitch;
+  long long out2_plane_pitch, out2_img_pitch;
 } c2m_conv3x3_desc;
 
 size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */

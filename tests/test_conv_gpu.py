@@ -176,6 +176,17 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
         H, W = got[k].shape[2:]
         assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, H + 1:].abs().max()) == 0
         assert float(bo.buf[:, :, 0].abs().max()) == 0 and float(bo.buf[:, :, W + 1:].abs().max()) == 0
+        assert bo.grouped8 is None   # a bare extractor asks for no group-major twin
+    # CorrespondenceGenerationArch's extractor also writes relu1_1 in the 8-channel group-major layout the large DynAgg
+    # gathers from: the same values, re-arranged, with the same zero border
+    vgg.grouped8_taps = ("relu1_1",)
+    with torch.no_grad():
+        got2 = vgg(img)
+    bo = c2m_amd.ops.bordered_of(got2["relu1_1"])
+    Bc, Hp, Wp, Cc = bo.buf.shape
+    assert torch.equal(got2["relu1_1"], got["relu1_1"])
+    assert torch.equal(bo.grouped8, bo.buf.view(Bc, Hp, Wp, Cc // 8, 8).permute(0, 3, 1, 2, 4).contiguous())
+    assert c2m_amd.ops.bordered_of(got2["relu2_1"]).grouped8 is None
     for k in ("dense_features1", "dense_features2"):
         assert got_e[k].is_contiguous() and got_e[k].shape == want_e[k].shape
         err = float((got_e[k] - want_e[k].detach()).abs().max())

@@ -60,6 +60,28 @@ def test_forward_matches_oracle(env, dev, shape):
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
 
 
+@pytest.mark.parametrize("shape", [SHAPES[2], SHAPES[5]])
+def test_forward_nhwc_group_major_input(env, dev, shape):
+    """Fused-path ABI with 8-channel deformable groups: gathering from the group-major twin of the bordered copy
+    (BorderedNHWC.grouped8, what the producing convolution writes) is the same arithmetic as gathering from the
+    channels-last copy -> bit-identical outputs, and both match the oracle."""
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 310)
+    args = (_t(w, dev), _t(b, dev), _t(off, dev), _t(msk, dev), dg)
+    bo = ops.BorderedNHWC(_t(x, dev))
+    assert bo.grouped8 is None
+    plain = ops.dcn_v2_forward_nhwc(bo, *args, nhwc_out=False)
+    bo.grouped8 = bo.buf.view(B, H + 3, W + 3, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+    grouped = ops.dcn_v2_forward_nhwc(bo, *args, nhwc_out=False)
+    assert torch.equal(plain, grouped)
+    want = oracle.dcn_v2_forward(x, w, b, off, msk, st, pd, dl, dg)
+    np.testing.assert_allclose(grouped.cpu().numpy(), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+    cl = ops.dcn_v2_forward_nhwc(bo, *args, act=ops.ACT_LRELU, slope=0.1)   # channels-last output + fused lrelu
+    np.testing.assert_allclose(cl.cpu().numpy(), np.where(want > 0, want, 0.1 * want), rtol=0,
+                               atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
 @pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[7]])
 def test_forward_bf16_mma_matches_bf16_oracle(env, dev, shape):
     """bf16-MFMA variant (fp32 tensors; staged input, weights and blended samples rounded to bf16, fp32 accumulation)
