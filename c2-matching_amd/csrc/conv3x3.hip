@@ -581,8 +581,8 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_wino_kernel(const float*
   wr[e0] = u;
 }
 
-// PX = pixel pairs per wave row: 32 -> workgroup tile 64 x 4 pixels (wave = one row), 16 -> 32 x 8 (wave = two rows of 16 pairs;
-// for maps whose width is a multiple of 32 but not of 64, e.g. the 160-wide LR-scale layers)
+// PX = pixel pairs per wave row: 16 -> workgroup tile 32 x 8 pixels (wave = two rows of 16 pairs; what the launcher uses:
+// smaller halo), 32 -> 64 x 4 (wave = one row; not instantiated any more, see c2m_conv3x3_nhwc_f32)
 template <int PX, int MODE>   // MODE 0: channels-last (+ activation, residuals); MODE 3: DCN offset/mask head
 __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   constexpr int RW = 32 / PX;                      // pixel rows per wave
@@ -931,7 +931,10 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
 
   conv::Params p;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
-  const bool wino64 = wino && d->W % 64 == 0;     // 64 x 4 tiles; otherwise (W % 32 == 0) 32 x 8 tiles
+  // 32 x 8 pixel tiles for every width.  The kernel also instantiates as 64 x 4 (PX = 32); measured on the decoder's shapes
+  // (B=16) that is 3-10 % slower -- its 66 x 6 halo re-reads 1.55x the tile from L2/HBM against 1.33x for 34 x 10, and the
+  // halo traffic is what this kernel stalls on (64->64 @640x640: 3.17 ms vs 2.93 ms; without input DMA 2.76 ms).
+  const bool wino64 = false;
   p.tiles_x = ceil_div(d->W, wino ? (wino64 ? 64 : 32) : conv::TW);
   p.tiles_y = ceil_div(d->H, wino && !wino64 ? 8 : conv::TH);
   p.nchunks = d->Cin / kch;
@@ -995,9 +998,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
       hipLaunchKernelGGL(kern, grid, dim3(256), ldsw, st, p);
     };
     if (d->out_mode == 3) {
-      if (wino64) gow(&conv::conv3x3_wino_kernel<32, 3>, done_w[0][1]); else gow(&conv::conv3x3_wino_kernel<16, 3>, done_w[1][1]);
+      gow(&conv::conv3x3_wino_kernel<16, 3>, done_w[1][1]);
     } else {
-      if (wino64) gow(&conv::conv3x3_wino_kernel<32, 0>, done_w[0][0]); else gow(&conv::conv3x3_wino_kernel<16, 0>, done_w[1][0]);
+      gow(&conv::conv3x3_wino_kernel<16, 0>, done_w[1][0]);
     }
   } else if (MW == 64) {
     switch (d->out_mode) {

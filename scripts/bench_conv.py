@@ -14,7 +14,8 @@ import c2m_amd  # noqa: E402
 ops = c2m_amd.ops
 SHAPES = [  # name, [cin per source], cout, hw, mode
     ("body 64->64 @160", [64], 64, 160, "nhwc"), ("body 64->64 @320", [64], 64, 320, "nhwc"),
-    ("body 64->64 @640", [64], 64, 640, "nhwc"), ("small_offset_conv1 320->256 @160", [64, 256], 256, 160, "nhwc"),
+    ("body 64->64 @640", [64], 64, 640, "nhwc"), ("body+res 64->64 @640", [64], 64, 640, "nhwc_res"),
+    ("body+res 64->64 @160", [64], 64, 160, "nhwc_res"), ("small_offset_conv1 320->256 @160", [64, 256], 256, 160, "nhwc"),
     ("small_offset_conv2 256->256 @160", [256], 256, 160, "nhwc"), ("head_small 320->64 @160", [64, 256], 64, 160, "nhwc"),
     ("tail_small 64->256 ps @160", [64], 256, 160, "pixel_shuffle"), ("medium_offset_conv1 192->128 @320", [64, 128], 128, 320, "nhwc"),
     ("large_offset_conv1 128->64 @640", [64, 64], 64, 640, "nhwc"), ("dcn head 64->216 @640", [64], 216, 640, "head"),
@@ -43,6 +44,8 @@ def main():
         def run():
             if mode == "head":
                 return ops.conv3x3_dcn_head(xs, w, b, 8, flow, hw // 160)
+            if mode == "nhwc_res":   # second conv of a ResidualBlockNoBN: no activation, + identity
+                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0])
             return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode)
         for _ in range(2):
             run()
