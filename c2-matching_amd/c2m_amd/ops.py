@@ -307,14 +307,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
                     raise _lib.C2MError(f"{name} must have the geometry of the output")
                 setattr(d, name, r.data_ptr())
         if out2_grouped8 is not None:
-            g2 = out2_grouped8
-            if (g2.dtype != torch.float32 or not g2.is_contiguous() or Cout % 8 != 0 or
-                    tuple(g2.shape) != (B, Cout // 8, H + 3, W + 3, 8) or g2.device != dev):
-                raise _lib.C2MError("out2_grouped8 must be a contiguous float32 [B, Cout/8, H+3, W+3, 8] buffer")
-            d.out2 = g2.data_ptr() + ((W + 3) + 1) * 8 * 4          # image pixel (0, 0) = bordered pixel (1, 1)
-            d.out2_row_pitch = (W + 3) * 8
-            d.out2_plane_pitch = (H + 3) * (W + 3) * 8
-            d.out2_img_pitch = (Cout // 8) * (H + 3) * (W + 3) * 8
+            d.out2, d.out2_row_pitch, d.out2_plane_pitch, d.out2_img_pitch = _grouped8_args(out2_grouped8, B, Cout, H, W, dev)
     elif out_mode == "pixel_shuffle":
         out = empty_nhwc(B, Cout // 4, 2 * H, 2 * W, dev)
         d.out_mode = 1
@@ -330,6 +323,50 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
     _conv_flops[1] += 2.0 * Cout * (6 if wino else 9) * Cin * H * W * B
+    return out
+
+
+def _grouped8_args(g2, B, Cout, H, W, dev):
+    if g2 is None:
+        return None, 0, 0, 0
+    if (g2.dtype != torch.float32 or not g2.is_contiguous() or Cout % 8 != 0 or
+            tuple(g2.shape) != (B, Cout // 8, H + 3, W + 3, 8) or g2.device != dev):
+        raise _lib.C2MError("out2_grouped8 must be a contiguous float32 [B, Cout/8, H+3, W+3, 8] buffer")
+    # image pixel (0, 0) = bordered pixel (1, 1); pitches in floats
+    return g2.data_ptr() + ((W + 3) + 1) * 8 * 4, (W + 3) * 8, (H + 3) * (W + 3) * 8, (Cout // 8) * (H + 3) * (W + 3) * 8
+
+
+def conv3x3_rgb64(image, weight, bias=None, act=ACT_NONE, slope=0.1, mean=None, std=None, out=None, out2_grouped8=None):
+    """First layer of an image tower (3 -> 64 channels; vgg conv1_1, conv_first) as its own im2col kernel:
+    out = act(conv3x3((image - mean) / std) + bias), channels_last [B,64,H,W].  image: [B,3,H,W] (any layout; read as
+    contiguous NCHW); mean / std: [1,3,1,1] buffers of the extractor or None.  out / out2_grouped8 as in conv3x3."""
+    x = image.float().contiguous()
+    if x.dim() != 4 or x.shape[1] != 3 or not x.is_cuda:
+        raise _lib.C2MError("conv3x3_rgb64: image must be a GPU tensor [B,3,H,W]")
+    if tuple(weight.shape) != (64, 3, 3, 3):
+        raise _lib.C2MError("conv3x3_rgb64: weight must be [64,3,3,3]")
+    B, _, H, W = x.shape
+    dev = x.device
+    w = _dev_f32(weight.detach(), "weight")
+    bias = _dev_f32(bias.detach(), "bias") if bias is not None else None
+    if (mean is None) != (std is None):
+        raise _lib.C2MError("conv3x3_rgb64: mean and std go together")
+    if mean is not None:
+        mean, std = _dev_f32(mean.detach().reshape(3), "mean"), _dev_f32(std.detach().reshape(3), "std")
+    if out is None:
+        out = empty_nhwc(B, 64, H, W, dev)
+    o = _nhwc_src(out, "out")
+    if tuple(out.shape) != (B, 64, H, W):
+        raise _lib.C2MError("conv3x3_rgb64: out must be [B,64,H,W]")
+    o2, o2_row, o2_plane, o2_img = _grouped8_args(out2_grouped8, B, 64, H, W, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().c2m_conv3x3_rgb64_f32(
+            _stream(), x.data_ptr(), B, H, W, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+            mean.data_ptr() if mean is not None else None, std.data_ptr() if std is not None else None, int(act),
+            float(slope), out.data_ptr(), o.pix_pitch, o.row_pitch, o.img_pitch, o2, o2_row, o2_plane, o2_img),
+            "c2m_conv3x3_rgb64_f32")
+    _conv_flops[0] += 2.0 * 64 * 27 * H * W * B
+    _conv_flops[1] += 2.0 * 64 * 28 * H * W * B
     return out
 
 
@@ -521,12 +558,24 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
     names = list(layers.keys())
     B, C, H, W = x.shape
     dev = x.device
-    cur = torch.zeros((B, 32, H, W), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
-    xin = x.float()
-    if mean is not None:
-        xin = (xin - mean) / std
-    cur[:, :C] = xin
+    first = layers[names[0]]
+    rgb64 = C == 3 and isinstance(first, torch.nn.Conv2d) and tuple(first.weight.shape) == (64, 3, 3, 3)
+    if rgb64:
+        cur = x      # the first layer reads the planar image itself and normalises it while staging
+    else:
+        cur = torch.zeros((B, 32, H, W), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+        xin = x.float()
+        if mean is not None:
+            xin = (xin - mean) / std
+        cur[:, :C] = xin
     out, k = {}, 0
+
+    def conv(k_, src, layer_, **kw):
+        if k_ == 0 and rgb64:
+            kw.pop("algo", None)
+            return conv3x3_rgb64(src, layer_.weight, layer_.bias, mean=mean, std=std, **kw)
+        return conv3x3(src, layer_.weight, layer_.bias, **kw)
+
     while k < len(names):
         name, layer = names[k], layers[names[k]]
         if isinstance(layer, torch.nn.Conv2d):
@@ -544,13 +593,12 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
             elif tap_name is not None:
                 bo = _bordered_empty(Bc, layer.out_channels, Hc, Wc, dev, grouped8=tap_name in grouped8_taps)
                 view = bo.interior()
-                conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out=view,
-                        out2_grouped8=bo.grouped8)
+                conv(k, cur, layer, act=ACT_RELU if relu else ACT_NONE, out=view, out2_grouped8=bo.grouped8)
                 view._c2m_bordered = bo
                 out[tap_name] = view
                 cur = view
             else:
-                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE)
+                cur = conv(k, cur, layer, act=ACT_RELU if relu else ACT_NONE)
             k += 2 if relu else 1
         elif isinstance(layer, torch.nn.MaxPool2d):
             cur = torch.nn.functional.max_pool2d(cur, layer.kernel_size, layer.stride, layer.padding)

@@ -849,6 +849,167 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First layer of an image tower: 3 input channels (vgg conv1_1, vgg_arch.py:107-123; conv_first, ref_restoration_arch.py:30)
+// -> 64 output channels.  K = 27 does not fill the 32-channel chunks of conv3x3_kernel (which then multiplies 29 zero
+// channels per tap: 2.1 ms for a 640 x 640 batch of 16), so this layer is an im2col GEMM of its own: 14 k-pairs per
+// 32 pixels x 64 channels, weights resident in registers, image tile (with the (x - mean) / std of the extractors applied
+// while it is staged; padding is zero in the NORMALISED domain, as in the reference) in LDS.  Memory-bound on its output.
+//   K order (so that both half-waves read LDS with one base register + immediates): pairs t = 0..8: (c, dy) = (t/3, t%3),
+//   hi -> dx = hi;  t = 9..11: c = t-9, dx = 2, hi -> dy = hi;  t = 12: dx = 2, dy = 2, hi -> c = hi;  t = 13: hi = 0 ->
+//   (c, dy, dx) = (2, 2, 2), hi = 1 -> zero weight.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace c3 {
+constexpr int CTW = 64, CTH = 8;                 // pixel tile of a workgroup (wave = two rows)
+constexpr int CHW = CTW + 2, CHH = CTH + 2;      // halo tile
+constexpr int PLANE = CHW * CHH;               // floats per staged channel
+constexpr int NEL = 3 * PLANE;                 // 1980
+constexpr int EPT = (NEL + 255) / 256;         // staged elements per thread (8)
+struct Params {
+  const float* in;      // [B][3][H][W]
+  const float* w;       // [64][3][3][3]
+  const float* bias;    // [64] or nullptr
+  const float* mean;    // [3] or nullptr: (x - mean[c]) / std[c] applied to the image first
+  const float* std_;
+  int B, H, W, tiles_x, tiles_y;
+  int act;
+  float slope;
+  float* out;           // channels-last, pitches in floats
+  int out_pix_pitch, out_row_pitch;
+  long long out_img_pitch;
+  float* out2;          // optional 8-channel group-major twin (see conv::Params::out2)
+  int out2_row_pitch;
+  long long out2_plane_pitch, out2_img_pitch;
+};
+}  // namespace c3
+
+__global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
+  using namespace c3;
+  __shared__ float tile[2][NEL];
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- weights: A operand of k-pair t, m-tile mt = W[mt*32 + j][k(t, hi)]
+  float wreg[14][2];
+#pragma unroll
+  for (int t = 0; t < 14; ++t) {
+    int c, dy, dx;
+    bool live = true;
+    if (t < 9) { c = t / 3; dy = t % 3; dx = hi; }
+    else if (t < 12) { c = t - 9; dy = hi; dx = 2; }
+    else if (t == 12) { c = hi; dy = 2; dx = 2; }
+    else { c = 2; dy = 2; dx = 2; live = hi == 0; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) wreg[t][mt] = live ? p.w[(size_t)(mt * 32 + j) * 27 + c * 9 + dy * 3 + dx] : 0.0f;
+  }
+  // LDS byte bases of this lane for the four pair families (pixel (row 0, column j) of the wave's first row, tap (0, 0, 0))
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&tile[0][0];
+  const unsigned pix = (unsigned)(j * 4);
+  const unsigned bA = pix + hi * 4;                 // dx = hi
+  const unsigned bB = pix + hi * (CHW * 4) + 8;     // dy = hi, dx = 2
+  const unsigned bC = pix + hi * (PLANE * 4) + (2 * CHW + 2) * 4;   // c = hi, (dy, dx) = (2, 2)
+  const unsigned bD = pix + (2 * PLANE + 2 * CHW + 2) * 4;          // (2, 2, 2) (hi = 1 multiplies a zero weight)
+
+  // ---- staging plan: element e = tid + 256 i of the halo tile -> (channel, halo row, halo column)
+  int s_off[EPT], s_ry[EPT], s_rx[EPT], s_c[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    const int c = e / PLANE, rem = e - c * PLANE;
+    s_c[i] = e < NEL ? c : -1;
+    s_ry[i] = rem / CHW;
+    s_rx[i] = rem - s_ry[i] * CHW;
+    s_off[i] = e;
+  }
+  float mean_[3] = {0.0f, 0.0f, 0.0f}, std3[3] = {1.0f, 1.0f, 1.0f};
+  if (p.mean) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { mean_[c] = p.mean[c]; std3[c] = p.std_[c]; }
+  }
+  const int ntile = p.tiles_x * p.tiles_y * p.B;
+  float stage[EPT];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
+    const float* ib = p.in + (size_t)b * 3 * p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int y = ty * CTH - 1 + s_ry[i], x = tx * CTW - 1 + s_rx[i];
+      const bool ok = s_c[i] >= 0 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      float v = 0.0f;
+      if (ok) {
+        v = ib[((size_t)s_c[i] * p.H + y) * p.W + x];
+        if (p.mean) v = (v - (s_c[i] == 0 ? mean_[0] : s_c[i] == 1 ? mean_[1] : mean_[2])) /
+                        (s_c[i] == 0 ? std3[0] : s_c[i] == 1 ? std3[1] : std3[2]);
+      }
+      stage[i] = v;
+    }
+  };
+  float bias4[2][4][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias4[mt][qd][e] = p.bias ? p.bias[mt * 32 + 8 * qd + 4 * hi + e] : 0.0f;
+
+  int t = blockIdx.x;
+  if (t < ntile) fetch(t);
+  for (int it = 0; t < ntile; t += gridDim.x, ++it) {
+    float* buf = tile[it & 1];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i)
+      if (s_c[i] >= 0) buf[s_off[i]] = stage[i];
+    __syncthreads();   // tile `it` staged; the buffer written next iteration was last read two barriers ago
+    if (t + (int)gridDim.x < ntile) fetch(t + gridDim.x);
+    const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
+    const unsigned tb = lds0 + (it & 1) * (NEL * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {   // the wave's groups: rows 2 wv + (g >> 1), columns 32 (g & 1) + j
+      const int row = 2 * wv + (g >> 1), col = 32 * (g & 1);
+      const unsigned gb = tb + (row * CHW + col) * 4;
+      float bv[14];
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        bv[k] = *(const __attribute__((address_space(3))) float*)(gb + bA + ((k / 3) * PLANE + (k % 3) * CHW) * 4);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bv[9 + k] = *(const __attribute__((address_space(3))) float*)(gb + bB + k * PLANE * 4);
+      bv[12] = *(const __attribute__((address_space(3))) float*)(gb + bC);
+      bv[13] = *(const __attribute__((address_space(3))) float*)(gb + bD);
+      f32x16 acc[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 14; ++k)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][mt], bv[k], acc[mt], 0, 0, 0);
+      const int y = ty * CTH + row, x = tx * CTW + col + j;
+      if (y < p.H && x < p.W) {
+        float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + 4 * hi;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[mt][4 * qd + e] + bias4[mt][qd][e];
+              if (p.act == 1) v[e] = fmaxf(v[e], 0.0f);
+              else if (p.act == 2) v[e] = fmaxf(v[e], v[e] * p.slope);
+            }
+            const int co = mt * 32 + 8 * qd + 4 * hi;
+            *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+            if (p.out2)
+              *reinterpret_cast<f32x4*>(p.out2 + (size_t)b * p.out2_img_pitch + (size_t)(co >> 3) * p.out2_plane_pitch +
+                                        (size_t)y * p.out2_row_pitch + x * 8 + (co & 7)) = v;
+          }
+      }
+    }
+  }
+}
+
 }  // namespace conv
 }  // namespace c2m
 
@@ -891,6 +1052,31 @@ extern "C" int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* w
   const long long total = (long long)(bytes / 4);
   hipLaunchKernelGGL(conv::conv3x3_relayout_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                      weight, Cin, Cout, total, wr);
+  return check_launch();
+}
+
+extern "C" int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, int B, int H, int W, const float* weight,
+                                     const float* bias, const float* mean, const float* std_, int act, float slope, float* out,
+                                     int out_pix_pitch, int out_row_pitch, long long out_img_pitch, float* out2,
+                                     int out2_row_pitch, long long out2_plane_pitch, long long out2_img_pitch) {
+  if (!image || !weight || !out || B <= 0 || H <= 0 || W <= 0 || (mean == nullptr) != (std_ == nullptr)) return C2M_ERR_INVALID_ARG;
+  if (act < 0 || act > 2 || (act == C2M_ACT_LEAKY_RELU && !(slope >= 0.0f && slope <= 1.0f))) return C2M_ERR_UNSUPPORTED;
+  if (out_pix_pitch % 4 != 0 || out_row_pitch % 4 != 0 || out_img_pitch % 4 != 0 || ((uintptr_t)out & 15)) return C2M_ERR_UNSUPPORTED;
+  if (out2 && (out2_row_pitch % 4 != 0 || out2_plane_pitch % 4 != 0 || out2_img_pitch % 4 != 0 || ((uintptr_t)out2 & 15)))
+    return C2M_ERR_UNSUPPORTED;
+  conv::c3::Params p;
+  p.in = image; p.w = weight; p.bias = bias; p.mean = mean; p.std_ = std_;
+  p.B = B; p.H = H; p.W = W;
+  p.tiles_x = ceil_div(W, conv::c3::CTW); p.tiles_y = ceil_div(H, conv::c3::CTH);
+  p.act = act; p.slope = slope; p.out = out; p.out_pix_pitch = out_pix_pitch; p.out_row_pitch = out_row_pitch;
+  p.out_img_pitch = out_img_pitch; p.out2 = out2; p.out2_row_pitch = out2_row_pitch; p.out2_plane_pitch = out2_plane_pitch;
+  p.out2_img_pitch = out2_img_pitch;
+  const long long ntile = (long long)p.tiles_x * p.tiles_y * B;
+  if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
+  hipStream_t st = as_stream(stream);
+  ProfileScope prof(C2M_KERNEL_CONV3X3, st);
+  // persistent workgroups (the weights stay in registers): 3 fit a CU (164 VGPRs), tiles strided over them
+  hipLaunchKernelGGL(conv::conv3x3_c3_kernel, dim3((unsigned)std::min<long long>(ntile, 768)), dim3(256), 0, st, p);
   return check_launch();
 }
 

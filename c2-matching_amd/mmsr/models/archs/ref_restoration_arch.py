@@ -36,9 +36,13 @@ class ContentExtractor(nn.Module):
         return self.body(self.lrelu(self.conv_first(x)))
 
     def forward_fused(self, x):
-        """x [B,3,h,w] (any layout) -> content feature, channels-last.  conv_first sees the image zero-padded to 32
-        channels (the kernel's chunk size; the weights are padded to match)."""
+        """x [B,3,h,w] (any layout) -> content feature, channels-last.  A 3 -> 64 conv_first runs on the first-layer
+        kernel; any other width sees the image zero-padded to 32 channels (the generic kernel's chunk size; the weights
+        are padded to match)."""
         B, C, H, W = x.shape
+        if tuple(self.conv_first.weight.shape) == (64, 3, 3, 3):
+            f = _ops.conv3x3_rgb64(x, self.conv_first.weight, self.conv_first.bias, act=_ops.ACT_LRELU, slope=0.1)
+            return _fused_body(self.body, f)
         x32 = torch.zeros((B, 32, H, W), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
         x32[:, :C] = x
         f = _ops.conv3x3(x32, self.conv_first.weight, self.conv_first.bias, act=_ops.ACT_LRELU, slope=0.1)

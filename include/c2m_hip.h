@@ -235,6 +235,18 @@ size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout);   /* 0 if unsupported
 int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
 
+/*
+ * First layer of an image tower -- 3 input channels, 64 output channels (vgg conv1_1, vgg_arch.py:107-123; conv_first,
+ * ref_restoration_arch.py:30): image [B][3][H][W] planar fp32, weight [64][3][3][3], bias [64] or NULL;
+ * mean / std [3] (both or neither): (image - mean[c]) / std[c] is applied first (vgg_arch.py:137-138), zero padding in the
+ * normalised domain.  Output channels-last with the given pitches (floats) + optional activation; out2: optional
+ * 8-channel group-major twin (see c2m_conv3x3_desc.out2).
+ */
+int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, int B, int H, int W, const float* weight,
+                          const float* bias, const float* mean, const float* std_, int act, float slope, float* out,
+                          int out_pix_pitch, int out_row_pitch, long long out_img_pitch, float* out2, int out2_row_pitch,
+                          long long out2_plane_pitch, long long out2_img_pitch);
+
 /* max_idx [B][hq][wq] int64 -> flow [B][hq][wq][2] fp32 (x, y) = (idx % wq - x, idx / wq - y): index_to_flow of
  * corres_generation_arch.py:29-46 for the whole batch, without the zero padding (the consumer bounds-checks). */
 int c2m_index_to_flow_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int hq, int wq, float* flow);

@@ -193,6 +193,31 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
         assert err < 2e-4 * max(1.0, float(want_e[k].abs().max())), (k, err)
 
 
+@pytest.mark.parametrize("B,H,W,act,norm", [(2, 40, 40, 1, True), (1, 37, 75, 2, False), (3, 8, 64, 0, True),
+                                             (1, 131, 200, 1, True), (2, 5, 3, 1, False)])
+def test_conv3x3_rgb64_first_layer(ops, dev, B, H, W, act, norm):
+    """The 3 -> 64 first-layer kernel (vgg conv1_1 / conv_first): (image - mean) / std, zero padding in the normalised
+    domain, conv + bias + activation, against float64 conv2d; plus the group-major twin and a bordered destination."""
+    img = torch.rand((B, 3, H, W), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    w = _rand((64, 3, 3, 3), dev, 6, 1.0 / np.sqrt(27))
+    b = _rand((64,), dev, 7)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    xin = ((img - mean) / std) if norm else img
+    want = _ref([xin], w, b, act, 0.1, [])
+    got = ops.conv3x3_rgb64(img, w, b, act=act, slope=0.1, mean=mean if norm else None, std=std if norm else None)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    tol = 1e-5 * max(1.0, float(want.abs().max()))
+    assert float((got.double() - want).abs().max()) < tol
+    bo = ops._bordered_empty(B, 64, H, W, dev, grouped8=True)
+    view = bo.interior()
+    ops.conv3x3_rgb64(img, w, b, act=act, slope=0.1, mean=mean if norm else None, std=std if norm else None, out=view,
+                      out2_grouped8=bo.grouped8)
+    assert torch.equal(view, got)
+    assert torch.equal(bo.grouped8, bo.buf.view(B, H + 3, W + 3, 8, 8).permute(0, 3, 1, 2, 4).contiguous())
+    assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, :, W + 1:].abs().max()) == 0
+
+
 WINO_CASES = [
     # B, [Cin per source], Cout, H, W, act, n residuals     (W % 32 == 0, Cout % 64 == 0, channels % 16 == 0)
     (2, [64], 64, 12, 64, 1, 0),
