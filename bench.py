@@ -164,8 +164,10 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None, gpu_idx=None):
     c2m_oracle.set_num_threads(min(threads, 64))
     tm = {}
     t0 = time.perf_counter()
-    sr, idx, _ = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm, idx_for_offsets=gpu_idx)
+    sr, idx, feats = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm, idx_for_offsets=gpu_idx)
     dt = time.perf_counter() - t0
+    cpu_baseline_restore.margins = (cpu_chain.mismatch_margins(feats["dense_features1"][0], feats["dense_features2"][0],
+                                                                gpu_idx[0], idx[0]) if gpu_idx is not None else [])
     return {"value": 1.0 / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"1 of the {lq.shape[0]} pairs of one step, whole forward (extractor, correlation as conv2d filters + "
                       f"running max, pre-offsets, VGG taps, RestorationNet with oracle DCNv2) on PyTorch-CPU + C oracle, "
@@ -383,6 +385,13 @@ def main():
             # parity of the timed GPU forward against the CPU chain on pair 0: index map (the CPU map comes from oneDNN
             # convolutions of the extractor, so fp32 near-ties may flip) and SR pixels given the same index map
             base["index_map_equal_fraction_gpu_vs_cpu_pair0"] = float((gpu_idx == idx_cpu).mean())
+            mg = cpu_baseline_restore.margins
+            base["index_map_mismatches_pair0"] = {
+                "queries": len(mg), "of": int(gpu_idx[0].size),
+                "max_abs_fp64_score_margin": max((abs(m[3]) for m in mg), default=0.0),
+                "note": "queries where the GPU and the CPU chain pick different ref patches, and the float64 score difference of "
+                        "the two picks on the CPU features: fp32 near-ties of the extractor features (two convolution "
+                        "implementations, same weights); the correlation kernel itself is bit-exact on identical features"}
             base["sr_max_abs_diff_gpu_vs_cpu_pair0"] = float((sr[0].cpu() - sr_cpu[0]).abs().max())
             line["cpu_baseline"] = base
         print(json.dumps(line))

@@ -205,7 +205,7 @@ class _WeightCache:
     def __init__(self):
         self._d = {}
 
-    def get(self, weight, pad_cin_to=None, rows=None, wino=False):
+    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3) layout
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
         slot = (id(weight), rows, wino)
         hit = self._d.get(slot)
@@ -222,13 +222,14 @@ class _WeightCache:
             Ci = pad_cin_to
         w = w.contiguous()
         L = _lib.lib()
-        nbytes = (L.c2m_conv3x3_relayout_wino_bytes if wino else L.c2m_conv3x3_relayout_bytes)(Ci, Co)
+        wino = int(wino)
+        nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
         if nbytes == 0:
             raise _lib.C2MError(f"conv3x3: unsupported channel counts Cin={Ci}, Cout={Co}" + (" for the Winograd kernel" if wino else
                                 " (input channels must be a multiple of 32)"))
         wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            fn = L.c2m_conv3x3_relayout_wino_f32 if wino else L.c2m_conv3x3_relayout_f32
+            fn = (L.c2m_conv3x3_relayout_f32, L.c2m_conv3x3_relayout_wino_f32, L.c2m_conv3x3_relayout_wino4_f32)[wino]
             _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
         self._d[slot] = (key, wr)
         return wr
@@ -254,6 +255,7 @@ def empty_nhwc(B, C, H, W, device):
 import os as _os
 
 _WINO = _os.environ.get("C2M_CONV_WINO", "1") != "0"
+_WINO4 = _os.environ.get("C2M_CONV_WINO4", "1") != "0"
 
 
 def _wino_ok(srcs, weight, out_mode, W):
@@ -262,28 +264,39 @@ def _wino_ok(srcs, weight, out_mode, W):
             all(s.shape[1] % 16 == 0 for s in srcs) and sum(s.shape[1] for s in srcs) == weight.shape[1])
 
 
+def _wino4_ok(srcs, weight, out_mode, W):
+    """Winograd F(4,3)-along-x kernel: as F(2,3) but whole 64-pixel tiles along x."""
+    return _WINO4 and W % 64 == 0 and _wino_ok(srcs, weight, out_mode, W)
+
+
 def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,
-            out2_grouped8=None):
+            out2_grouped8=None, fast=False):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
 
     srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
     the (zero-padded) weight is not accepted -- pad the tensor).  out_mode: "nhwc" -> channels_last [B,Cout,H,W];
     "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous.
     out2_grouped8: a zero-bordered group-major buffer [B,Cout/8,H+3,W+3,8] that receives a second copy of the output
-    (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only."""
+    (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only.
+    algo: None (auto: Winograd F(2,3) where the shapes allow, else direct), "direct", "winograd", "winograd4".  fast=True lets
+    the auto choice take the F(4,3) kernel (2x fewer matrix instructions, ~4x the rounding error of the direct kernel, still
+    ~1e-6 relative): the decoder asks for it, the extractors that feed the index search do not."""
     srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
     B, _, H, W = srcs[0].shape
     Cin = sum(s.shape[1] for s in srcs)
     Cout = weight.shape[0]
     dev = srcs[0].device
-    wino = _wino_ok(srcs, weight, out_mode, W) if algo is None else (algo == "winograd")
+    if algo is None:
+        wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
+    else:
+        wino = {"direct": 0, "winograd": 1, "winograd4": 2}[algo]
     if out2_grouped8 is not None:
-        if algo == "winograd" or out_mode != "nhwc":
+        if algo in ("winograd", "winograd4") or out_mode != "nhwc":
             raise _lib.C2MError("out2_grouped8 needs the direct kernel in nhwc mode")
-        wino = False
+        wino = 0
     wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None, wino=wino)
     d = _lib.Conv3x3Desc()
-    d.algo = 1 if wino else 0
+    d.algo = wino
     d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
     for k, s in enumerate(srcs):
         if tuple(s.shape[2:]) != (H, W) or s.shape[0] != B:
@@ -322,7 +335,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
-    _conv_flops[1] += 2.0 * Cout * (6 if wino else 9) * Cin * H * W * B
+    _conv_flops[1] += 2.0 * Cout * (9, 6, 4.5)[wino] * Cin * H * W * B
     return out
 
 
@@ -412,7 +425,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         wino = _WINO and (c1 - c0) % 64 == 0 and W % 32 == 0 and all(s_.shape[1] % 16 == 0 for s_ in srcs)
         wr = _wcache.get(weight, rows=(c0, c1), wino=wino)
         d = _lib.Conv3x3Desc()
-        d.algo = 1 if wino else 0
+        d.algo = wino
         d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, c1 - c0, len(srcs)
         for k, s in enumerate(srcs):
             d.src[k] = _nhwc_src(s, f"src{k}")

@@ -850,6 +850,352 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
 }
 
 
+// =====================================================================================================================
+// Winograd F(4,3) along x (mode 0 only).  Output pixels are produced in horizontal QUADS: six transform positions per row
+// tap instead of the 12 k-steps a direct quad costs -- 2x fewer matrix instructions than the direct kernel, 1.33x fewer
+// than F(2,3).  U = G g (precomputed by conv3x3_relayout_wino4_kernel), V = B^T d over the six input columns 4t-1 .. 4t+4,
+// Y = A^T M with
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Six accumulator sets = 192 registers per lane: the kernel runs ONE wave per SIMD (one workgroup of 4 waves per CU, up to
+// 512 registers per lane), so nothing of another wave hides its latencies -- operand reads, the input transform (packed
+// fp32, ~0.25 VALU instruction per MFMA) and all DMA waits are scheduled under its own MFMAs; only the tile epilogue is
+// exposed (~5 %).  Same DMA / ring / barrier machinery as the F(2,3) kernel.
+//   workgroup = 4 waves = 64 x 8 pixels (wave = two rows of 16 quads), halo 66 x 10; chunk = 16 input channels;
+//   unit = (chunk, dy, three xi) = 12 KiB of weights, 48 MFMAs per wave; bias enters through the initial value of M1.
+// fp32 throughout; the transforms' rounding puts the result ~4x further from the exact value than the direct kernel
+// (5e-6 against 1.5e-6 at |y| ~ 5): used for the decoder, not for the extractors that feed the index search.
+// =====================================================================================================================
+namespace wino4 {
+constexpr int KC = 16;
+constexpr int TWX = 64, THY = 8;
+constexpr int HWc = TWX + 2, HHr = THY + 2;
+constexpr int NIN_REAL = (HWc * HHr * 4 + 63) / 64;   // 42 DMA instructions of 64 x 16 bytes
+constexpr int NIN_W = (NIN_REAL + 3) / 4;             // per wave
+constexpr int IN_BYTES = NIN_REAL * 1024;
+constexpr int WIMG = 64 * 64;                         // one (dy, xi) weight image: 64 couts x 16 k
+constexpr int XPU = 3;                                // transform positions per unit
+constexpr int WUNIT = XPU * WIMG;
+constexpr int NRING = 3;
+constexpr int UPC = 6;                                // units per chunk: 3 row taps x 2 halves of the six positions
+static_assert(UPC % NRING == 0, "ring slot of a unit must be a compile-time constant");
+}  // namespace wino4
+
+// weights W[Cout][Cin][3][3] -> Wr[cb][chunk][dy][xi 6][row 64][slot 4][e 4], slot = q ^ ((row >> 2) & 3),
+// value = U[cb*64 + row][chunk*16 + 4q + e][dy][xi]
+__global__ void __launch_bounds__(256) conv3x3_relayout_wino4_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                                       long long total, float* __restrict__ wr) {
+  const long long e0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e0 >= total) return;
+  const int e = (int)(e0 & 3), slot = (int)((e0 >> 2) & 3);
+  long long r = e0 >> 4;
+  const int row = (int)(r & 63); r >>= 6;
+  const int xi = (int)(r % 6); r /= 6;
+  const int dy = (int)(r % 3); r /= 3;
+  const int nch = Cin / wino4::KC;
+  const int chunk = (int)(r % nch);
+  const int cb = (int)(r / nch);
+  const int q = slot ^ ((row >> 2) & 3);
+  const int co = cb * 64 + row, ci = chunk * wino4::KC + 4 * q + e;
+  float u = 0.0f;
+  if (co < Cout) {
+    const float* g = w + ((size_t)co * Cin + ci) * 9 + dy * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    switch (xi) {
+      case 0: u = g0 * 0.25f; break;
+      case 1: u = ((g0 + g1) + g2) * (-1.0f / 6.0f); break;
+      case 2: u = ((g0 - g1) + g2) * (-1.0f / 6.0f); break;
+      case 3: u = (g0 * (1.0f / 24.0f) + g1 * (1.0f / 12.0f)) + g2 * (1.0f / 6.0f); break;
+      case 4: u = (g0 * (1.0f / 24.0f) - g1 * (1.0f / 12.0f)) + g2 * (1.0f / 6.0f); break;
+      default: u = g2; break;
+    }
+  }
+  wr[e0] = u;
+}
+
+#define C2M_W4_LOAD_A(K)                                                                                              \
+  case K:                                                                                                             \
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                     \
+                 : "=&v"(a[0]), "=&v"(a[1])                                                                           \
+                 : "v"(aaddr[g]), "n"((K) * wino4::WIMG), "n"((K) * wino4::WIMG + 2048)                               \
+                 : "memory");                                                                                         \
+    break;
+
+template <int ABL>   // 0; > 0: timing-only ablations (wrong results): 1 no barriers / DMA waits, 2 no epilogue, 3 no halo DMA
+__global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
+  constexpr int KC = wino4::KC, TWX = wino4::TWX, THY = wino4::THY, HWc = wino4::HWc, HHr = wino4::HHr;
+  constexpr int NIN_REAL = wino4::NIN_REAL, NIN_W = wino4::NIN_W, IN_BYTES = wino4::IN_BYTES, WUNIT = wino4::WUNIT;
+  constexpr int XPU = wino4::XPU, NRING = wino4::NRING, UPC = wino4::UPC;
+  constexpr int MT = 2;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  // [in0 | in1 | w ring x3 | dummy 1 KiB | bias 64 floats]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned in_base = lds0, w_base = lds0 + 2 * IN_BYTES, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
+
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = j & 15, prow = wv * 2 + (j >> 4);   // the lane's pixel quad: columns 4pt .. 4pt+3 of row prow
+  const int ntile = p.tiles_x * p.tiles_y * p.B;
+  const int tile_first = xcd_remap(blockIdx.x, gridDim.x) * p.tpw;
+  const int ntl = min(p.tpw, ntile - tile_first);
+  const int cb = blockIdx.y;
+  const int UT = p.nchunks * UPC;       // units per tile
+  const int G = ntl * p.nchunks;        // chunks of this workgroup
+  const int T = G * UPC;                // units of this workgroup
+
+  // ---- DMA plumbing: weights, 3 KiB per wave and unit
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.wr + (long long)cb * UT * (WUNIT / 4), (unsigned)UT * WUNIT);
+  const unsigned wvoff = (wv * 192 + l) * 16;
+  int wsoff = 0;
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {
+    const unsigned dst = w_base + slot * WUNIT + wv * 3072;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff, 2048, 0);
+    wsoff += WUNIT;
+    if (wsoff == UT * WUNIT) wsoff = 0;
+  };
+  // ---- halo tile (as conv3x3_wino_kernel): instruction n = wave + 4 * slot covers pieces [64n, 64n + 64)
+  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+    b = tile / (p.tiles_x * p.tiles_y);
+    x0 = tx * TWX;
+    y0 = ty * THY;
+  };
+  unsigned ivoff[NIN_W];
+  int ib = 0, iy0 = 0, ix0 = 0;
+  __amdgpu_buffer_rsrc_t rs0, rs1;
+  const int qdma = (l & 3) ^ ((l >> 4) & 3);
+  auto set_source = [&](const Src& S) __attribute__((always_inline)) {
+    const int pl0 = 16 * wv + (l >> 2);
+    int ry = pl0 / HWc, rx = pl0 - ry * HWc;
+#pragma unroll
+    for (int sl = 0; sl < NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
+      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+      const bool ok = n < NIN_REAL && ry < HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * qdma) * 4u : kOOB;
+      rx += 64;
+      if (rx >= HWc) { rx -= HWc; ry += 1; }
+    }
+  };
+  auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
+    const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
+    return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
+  };
+  auto issue_in = [&](int gc) __attribute__((always_inline)) {
+    const int it = gc / p.nchunks, c0 = (gc - it * p.nchunks) * KC;
+    const bool first = c0 < p.src[0].C;
+    if (c0 == 0) {
+      tile_coords(tile_first + it, ib, iy0, ix0);
+      rs0 = src_rsrc(p.src[0], ib);
+      rs1 = src_rsrc(p.src[1], ib);
+      set_source(p.src[0]);
+    } else if (c0 == p.src[0].C) {
+      set_source(p.src[1]);
+    }
+    const unsigned buf = in_base + (gc & 1) * IN_BYTES;
+    const int soff = (first ? c0 : c0 - p.src[0].C) * 4;
+#pragma unroll
+    for (int sl = 0; sl < NIN_W; ++sl) {
+      const int n = wv + 4 * sl;
+      const unsigned dst = n < NIN_REAL ? buf + n * 1024 : dummy;
+      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
+    }
+  };
+
+  const int co_lane = cb * 64 + 4 * hi;
+  if (tid < 64) {
+    const int co = cb * 64 + tid;
+    *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+  }
+  __syncthreads();
+  // accumulators: M[xi][mt]; A^T (b, 0, 0, 0, 0, 0 in M1) = (b, b, b, b): the bias is the initial value of M1
+  f32x16 M[6][MT];
+  auto init_m = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (mt * 32 + 8 * qd + 4 * hi) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int xi = 0; xi < 6; ++xi) M[xi][mt][4 * qd + e] = 0.0f;
+          M[1][mt][4 * qd + e] = bv[e];
+        }
+      }
+  };
+  init_m();
+
+  // A operand: row = cout j (+32 mt), piece 2g + hi, slot q ^ ((row >> 2) & 3); + ring slot * WUNIT + xi_local * WIMG
+  unsigned aaddr[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) aaddr[g] = w_base + j * 64 + (((2 * g + hi) ^ ((j >> 2) & 3)) << 4);
+  auto load_a = [&](int uc, int st, f32x4 (&a)[MT]) __attribute__((always_inline)) {   // st = 2 * xi_local + g
+    const int g = st & 1;
+    switch ((uc % NRING) * XPU + (st >> 1)) {
+      C2M_W4_LOAD_A(0) C2M_W4_LOAD_A(1) C2M_W4_LOAD_A(2) C2M_W4_LOAD_A(3) C2M_W4_LOAD_A(4)
+      C2M_W4_LOAD_A(5) C2M_W4_LOAD_A(6) C2M_W4_LOAD_A(7) C2M_W4_LOAD_A(8)
+      default: break;
+    }
+  };
+  auto wait_a = [&](auto n, f32x4 (&a)[MT]) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+  };
+  // input transform of one row tap: six raw b128 reads per k-quad (input columns 4t-1 .. 4t+4 of the lane's quad)
+  f32x4 V[6][2], d[2][6];
+  auto issue_raw = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bcol = 0; bcol < 6; ++bcol) {
+        const int pl = (prow + dy) * HWc + 4 * pt + bcol;
+        const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
+      }
+  };
+  auto wait_raw = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[0][4]), "+v"(d[0][5]), "+v"(d[1][0]),
+                   "+v"(d[1][1]), "+v"(d[1][2]), "+v"(d[1][3]), "+v"(d[1][4]), "+v"(d[1][5]));
+  };
+  auto vcomp = [&]() __attribute__((always_inline)) {
+    const f32x4 c4 = {4.0f, 4.0f, 4.0f, 4.0f}, cm4 = {-4.0f, -4.0f, -4.0f, -4.0f}, cm5 = {-5.0f, -5.0f, -5.0f, -5.0f},
+                c2 = {2.0f, 2.0f, 2.0f, 2.0f}, cm2 = {-2.0f, -2.0f, -2.0f, -2.0f};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 t1 = __builtin_elementwise_fma(cm4, d[g][2], d[g][4]);   // d4 - 4 d2
+      const f32x4 t2 = __builtin_elementwise_fma(cm4, d[g][1], d[g][3]);   // d3 - 4 d1
+      const f32x4 t3 = d[g][4] - d[g][2];
+      const f32x4 t4 = d[g][3] - d[g][1];
+      V[0][g] = __builtin_elementwise_fma(c4, d[g][0], __builtin_elementwise_fma(cm5, d[g][2], d[g][4]));
+      V[1][g] = t1 + t2;
+      V[2][g] = t1 - t2;
+      V[3][g] = __builtin_elementwise_fma(c2, t4, t3);
+      V[4][g] = __builtin_elementwise_fma(cm2, t4, t3);
+      V[5][g] = __builtin_elementwise_fma(c4, d[g][1], __builtin_elementwise_fma(cm5, d[g][3], d[g][5]));
+    }
+  };
+
+  issue_in(0);
+  if (G > 1) issue_in(1);
+  issue_w(0);
+  issue_w(1);
+  issue_w(2);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 a_s[2][MT];
+  issue_raw(in_base, 0);
+  for (int it = 0, gc = 0; it < ntl; ++it) {
+    for (int c = 0; c < p.nchunks; ++c, ++gc) {
+      const unsigned ibuf = in_base + (gc & 1) * IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * IN_BYTES;
+      const bool more_in = gc + 1 < G;
+#pragma unroll
+      for (int uc = 0; uc < UPC; ++uc) {
+        const int gu = gc * UPC + uc;
+        const int dy = uc >> 1, xh = uc & 1;          // row tap, which half of the transform positions (xi = 3 xh ..)
+        const bool next_group = gu + 2 - xh < T;       // a group (chunk, dy) follows this one
+        if (xh == 0) {
+          wait_raw();
+          load_a(uc, 0, a_s[0]);
+          vcomp();
+        }
+#pragma unroll
+        for (int st = 0; st < 2 * XPU; ++st) {         // step = (xi_local, g)
+          const int cur = st & 1, nxt = cur ^ 1;
+          const int xi = XPU * xh + (st >> 1), g = st & 1;
+          if (st < 2 * XPU - 1) {
+            load_a(uc, st + 1, a_s[nxt]);
+            wait_a(std::integral_constant<int, 2>(), a_s[cur]);
+          } else if (xh == 1) {
+            // last step of the group: the next group's raw values are fetched now (its operands at the top of its first unit)
+            if (next_group) {
+              if (dy < 2) issue_raw(ibuf, dy + 1);
+              else issue_raw(ibuf_next, 0);
+              wait_a(std::integral_constant<int, 12>(), a_s[cur]);
+            } else {
+              wait_a(std::integral_constant<int, 0>(), a_s[cur]);
+            }
+          } else {
+            load_a(uc + 1, 0, a_s[nxt]);               // next unit of the same group
+            wait_a(std::integral_constant<int, 2>(), a_s[cur]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              M[xi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[cur][mt][e], V[xi][g][e], M[xi][mt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (gu + 1 < T) {
+          if constexpr (ABL != 1) {
+            if (uc == 0 && gc >= 1 && more_in) wait_vmcnt<NIN_W>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+          }
+          if (gu + 3 < T) issue_w(uc % NRING);
+          if (ABL != 3 && uc == UPC - 1 && gc + 2 < G) issue_in(gc + 2);
+        }
+      }
+    }
+    // ---- tile epilogue: Y = A^T M (bias already inside M1), activation, residuals, four channels-last pixels per lane
+    int b, y0, x0;
+    tile_coords(tile_first + it, b, y0, x0);
+    asm volatile("" : "+s"(b), "+s"(y0), "+s"(x0));
+    const int y = y0 + prow, x = x0 + 4 * pt;
+    const bool pok = y < p.H && x < p.W;   // W % 64 == 0: the quad is inside or outside as a whole
+    const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
+    const float* r1 = p.res1 ? p.res1 + opix + co_lane : nullptr;
+    const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
+    float* ob = p.out + opix + co_lane;
+    if (ABL == 2 && it > 0) { init_m(); continue; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int co = co_lane + mt * 32 + 8 * qd;
+        f32x4 yv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * qd + e;
+          const float m0 = M[0][mt][r], m1 = M[1][mt][r], m2 = M[2][mt][r], m3 = M[3][mt][r], m4 = M[4][mt][r], m5 = M[5][mt][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          yv[0][e] = (m0 + s12) + s34;
+          yv[1][e] = __builtin_fmaf(2.0f, d34, d12);
+          yv[2][e] = __builtin_fmaf(4.0f, s34, s12);
+          yv[3][e] = __builtin_fmaf(8.0f, d34, d12) + m5;
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[k][e] = fmaxf(yv[k][e], 0.0f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[k][e] = fmaxf(yv[k][e], yv[k][e] * p.slope);
+        }
+        if (pok && co + 3 < p.Cout) {
+          const int o = mt * 32 + 8 * qd;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (r1) yv[k] += *reinterpret_cast<const f32x4*>(r1 + k * p.out_pix_pitch + o);
+            if (r2) yv[k] += *reinterpret_cast<const f32x4*>(r2 + k * p.out_pix_pitch + o);
+            *reinterpret_cast<f32x4*>(ob + k * p.out_pix_pitch + o) = yv[k];
+          }
+        }
+      }
+    init_m();
+  }
+}
+#undef C2M_W4_LOAD_A
+
 // ---------------------------------------------------------------------------------------------------------------------
 // First layer of an image tower: 3 input channels (vgg conv1_1, vgg_arch.py:107-123; conv_first, ref_restoration_arch.py:30)
 // -> 64 output channels.  K = 27 does not fill the 32-channel chunks of conv3x3_kernel (which then multiplies 29 zero
@@ -1040,6 +1386,21 @@ extern "C" int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight
   return check_launch();
 }
 
+extern "C" size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cin % conv::wino4::KC != 0 || Cout % 64 != 0) return 0;
+  return (size_t)(Cout / 64) * (Cin / conv::wino4::KC) * 18 * conv::wino4::WIMG;   // 3 row taps x 6 transform positions
+}
+
+extern "C" int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr) {
+  if (!weight || !wr) return C2M_ERR_INVALID_ARG;
+  const size_t bytes = c2m_conv3x3_relayout_wino4_bytes(Cin, Cout);
+  if (bytes == 0) return C2M_ERR_UNSUPPORTED;
+  const long long total = (long long)(bytes / 4);
+  hipLaunchKernelGGL(conv::conv3x3_relayout_wino4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     weight, Cin, Cout, total, wr);
+  return check_launch();
+}
+
 extern "C" size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % conv::wino::KC != 0 || Cout % 64 != 0) return 0;
   return (size_t)(Cout / 64) * (Cin / conv::wino::KC) * 12 * conv::wino::WIMG;   // 3 row taps x 4 transform positions
@@ -1092,9 +1453,11 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   if (!d || !d->wr || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->nsrc < 1 ||
       d->nsrc > 2 || !d->src[0].ptr || (d->nsrc == 2 && !d->src[1].ptr))
     return C2M_ERR_INVALID_ARG;
-  const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X;
+  const bool wino4 = d->algo == C2M_CONV_WINOGRAD_F43X;
+  const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X || wino4;   // both: 16-channel chunks, 64-cout blocks
   if (d->algo != 0 && !wino) return C2M_ERR_INVALID_ARG;
   if (wino && ((d->out_mode != 0 && d->out_mode != 3) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
+  if (wino4 && (d->out_mode != 0 || d->W % 64 != 0)) return C2M_ERR_UNSUPPORTED;
   const int kch = wino ? conv::wino::KC : conv::KCH;
   int csum = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -1121,8 +1484,8 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   // (B=16) that is 3-10 % slower -- its 66 x 6 halo re-reads 1.55x the tile from L2/HBM against 1.33x for 34 x 10, and the
   // halo traffic is what this kernel stalls on (64->64 @640x640: 3.17 ms vs 2.93 ms; without input DMA 2.76 ms).
   const bool wino64 = false;
-  p.tiles_x = ceil_div(d->W, wino ? (wino64 ? 64 : 32) : conv::TW);
-  p.tiles_y = ceil_div(d->H, wino && !wino64 ? 8 : conv::TH);
+  p.tiles_x = ceil_div(d->W, wino4 ? conv::wino4::TWX : wino ? (wino64 ? 64 : 32) : conv::TW);
+  p.tiles_y = ceil_div(d->H, wino4 ? conv::wino4::THY : wino && !wino64 ? 8 : conv::TH);
   p.nchunks = d->Cin / kch;
   for (int s = 0; s < 2; ++s) {
     const int k = s < d->nsrc ? s : 0;
@@ -1154,14 +1517,16 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
   }
   // tiles per workgroup: long streams amortise the set-up and the first DMA wait, but the launch is only as fast as its
-  // last round of 512 resident workgroups (2 per CU): take the tpw <= 10 with the fewest "rounds x tiles" (ties: the
-  // longer stream), e.g. 51200 tiles -> 10 (10 full rounds), 12800 -> 5 (5 full rounds).  C2M_CONV_TPW overrides.
+  // last round of 512 resident workgroups (2 per CU; the F(4,3) kernel: 256, 1 per CU): take the tpw <= 10 with the fewest
+  // "rounds x tiles" (ties: the longer stream), e.g. 51200 tiles -> 10 (10 full rounds), 12800 -> 5 (5 full rounds).
+  // C2M_CONV_TPW overrides.
   static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
   const int ncb = ceil_div(d->Cout, MW);
+  const long long resident = wino4 ? 256 : 512;
   long long tpw = 1, best = -1;
   for (long long t = 1; t <= 10; ++t) {
     const long long wgs = ((ntile + t - 1) / t) * ncb;
-    const long long cost = ((wgs + 511) / 512) * t;
+    const long long cost = ((wgs + resident - 1) / resident) * t;
     if (best < 0 || cost <= best) { best = cost; tpw = t; }
   }
   if (env_tpw > 0) tpw = env_tpw;
@@ -1176,7 +1541,22 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
   };
   static unsigned long long done[2][4] = {};
-  if (wino) {
+  if (wino4) {
+    static unsigned long long done_w4 = 0;
+    const size_t lds4 = 2 * conv::wino4::IN_BYTES + conv::wino4::NRING * conv::wino4::WUNIT + 1024 + 256;
+    static const int abl = [] { const char* e = getenv("C2M_CONV_ABL"); return e ? atoi(e) : 0; }();
+    static unsigned long long done_abl[4] = {};
+    auto go4 = [&](auto kern, unsigned long long& dn) {
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds4, dn)) == C2M_OK)
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds4, st, p);
+    };
+    switch (abl) {
+      case 1: go4(&conv::conv3x3_wino4_kernel<1>, done_abl[1]); break;
+      case 2: go4(&conv::conv3x3_wino4_kernel<2>, done_abl[2]); break;
+      case 3: go4(&conv::conv3x3_wino4_kernel<3>, done_abl[3]); break;
+      default: go4(&conv::conv3x3_wino4_kernel<0>, done_w4); break;
+    }
+  } else if (wino) {
     static unsigned long long done_w[2][2] = {};
     const size_t ldsw = 2 * conv::wino::IN_BYTES + conv::wino::NRING * conv::wino::WUNIT + 1024 + 256;
     auto gow = [&](auto kern, unsigned long long& dn) {

@@ -55,11 +55,12 @@ def _fusable_body(body):
 
 def _fused_body(body, f, skip=None):
     """16 x (x + conv2(relu(conv1(x)))) (arch_util.py:128-136), two launches per block; `skip` (the stage input,
-    ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue."""
+    ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue.  fast=True: decoder
+    convolutions may take the Winograd F(4,3) kernel (ops.conv3x3) where the map is a whole number of 64-pixel tiles wide."""
     n = len(body)
     for k, blk in enumerate(body):
-        t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU)
-        f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None)
+        t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU, fast=True)
+        f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None, fast=True)
     return f
 
 
@@ -104,7 +105,7 @@ class DynamicAggregationRestoration(nn.Module):
         return x
 
     def _stage_fused(self, name, x, ref_feat, flow, scale):
-        lrelu = dict(act=_ops.ACT_LRELU, slope=0.1)
+        lrelu = dict(act=_ops.ACT_LRELU, slope=0.1, fast=True)
         ref = _ops.BorderedNHWC(ref_feat)          # one copy serves the offset conv (as a source) and the DCN gathers
         c1, c2 = getattr(self, f'{name}_offset_conv1'), getattr(self, f'{name}_offset_conv2')
         of = _ops.conv3x3([x, ref.interior()], c1.weight, c1.bias, **lrelu)

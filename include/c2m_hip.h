@@ -192,7 +192,7 @@ typedef struct c2m_conv_src {
   long long img_pitch;   /* floats between samples */
 } c2m_conv_src;
 
-enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1 };
+enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2 };
 enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3 };
 
 typedef struct c2m_conv3x3_desc {
@@ -218,7 +218,11 @@ typedef struct c2m_conv3x3_desc {
   double* abs_sum;         /* DCN_HEAD: C2M_ABS_SUM_SLOTS partial sums of |raw offset| (caller zeroes), or NULL */
   int algo;                /* C2M_CONV_DIRECT (0) or C2M_CONV_WINOGRAD_F23X: Winograd F(2,3) along x -- 1.5x fewer matrix
                               instructions; NHWC mode, Cout % 64 == 0, even W, channels % 16 == 0; `wr` must then come from
-                              c2m_conv3x3_relayout_wino_f32.  fp32; differs from the direct kernel by transform rounding */
+                              c2m_conv3x3_relayout_wino_f32.  fp32; differs from the direct kernel by transform rounding.
+                              C2M_CONV_WINOGRAD_F43X (2): Winograd F(4,3) along x -- 2x fewer matrix instructions; NHWC mode only,
+                              Cout % 64 == 0, W % 64 == 0, channels % 16 == 0, `wr` from c2m_conv3x3_relayout_wino4_f32; its
+                              transforms put the result ~4x further from the exact value than the direct kernel (still
+                              ~1e-6 relative): meant for the decoder, not for the extractors that feed the index search */
   int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
   int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
                               head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
@@ -233,6 +237,8 @@ size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is 
 int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight /* [Cout][Cin][3][3] */, int Cin, int Cout, float* wr);
 size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout);   /* 0 if unsupported (Cin % 16, Cout % 64) */
 int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
+size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout);  /* 0 if unsupported (Cin % 16, Cout % 64) */
+int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
 
 /*

@@ -44,6 +44,28 @@ def cpu_copy(net_g):
     return g
 
 
+def mismatch_margins(feats1, feats2, idx_a, idx_b):
+    """For every query where two index maps of ONE pair disagree: float64 score of both picks on the given (CPU) features,
+    as ref_map_util.py:52-76 scores them (ref patch divided by its norm + 1e-5).  -> list of (query, pick_a, pick_b,
+    score_a - score_b): |margin| at fp32 rounding level (<~ 5e-6) = a near-tie either implementation of
+    the extractor convolutions may resolve either way."""
+    C, h, w = feats1.shape
+    f1 = F.normalize(feats1.reshape(C, -1), dim=0).view(C, h, w).double().numpy()
+    f2 = F.normalize(feats2.reshape(C, -1), dim=0).view(C, h, w).double().numpy()
+    wq = w - 2
+    out = []
+    for q in np.argwhere(np.asarray(idx_a) != np.asarray(idx_b)):
+        qy, qx = int(q[0]), int(q[1])
+        patch = f1[:, qy:qy + 3, qx:qx + 3]
+        sc = []
+        for n in (int(idx_a[qy, qx]), int(idx_b[qy, qx])):
+            ry, rx = divmod(n, wq)
+            r = f2[:, ry:ry + 3, rx:rx + 3]
+            sc.append(float((patch * r).sum() / (np.sqrt((r * r).sum()) + 1e-5)))
+        out.append(((qy, qx), int(idx_a[qy, qx]), int(idx_b[qy, qx]), sc[0] - sc[1]))
+    return out
+
+
 @torch.no_grad()
 def correspondence_cpu(feats1, feats2, use_conv_algorithm=True):
     """dense features [B,C,h,w] x2 -> (max_idx int64 [B,h-2,w-2], pre_offset dict) as corres_generation_arch.py:48-117."""

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--fast", action="store_true", help="let ops.conv3x3 take the Winograd F(4,3) kernel (decoder setting)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -45,8 +46,8 @@ def main():
             if mode == "head":
                 return ops.conv3x3_dcn_head(xs, w, b, 8, flow, hw // 160)
             if mode == "nhwc_res":   # second conv of a ResidualBlockNoBN: no activation, + identity
-                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0])
-            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode)
+                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0], fast=args.fast)
+            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode, fast=args.fast)
         for _ in range(2):
             run()
         c2m_amd.profile_enable(True)

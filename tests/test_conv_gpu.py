@@ -193,6 +193,38 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
         assert err < 2e-4 * max(1.0, float(want_e[k].abs().max())), (k, err)
 
 
+WINO4_CASES = [
+    # B, [Cin per source], Cout, H, W, act, n residuals     (W % 64 == 0, Cout % 64 == 0, channels % 16 == 0)
+    (2, [64], 64, 12, 64, 1, 0),
+    (1, [64], 64, 9, 128, 0, 2),         # ragged tile rows, two residuals
+    (2, [64, 64], 64, 8, 64, 2, 0),      # two sources (head_large: cat(x, swapped))
+    (1, [96], 128, 6, 64, 0, 1),         # 6 chunks of 16, two cout blocks
+    (1, [64], 64, 40, 320, 1, 1),        # several tiles per workgroup stream
+    (1, [64, 128], 128, 19, 192, 2, 0),  # medium_offset_conv1 geometry
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv3x3_winograd_f43_matches_fp64(ops, dev, case):
+    """Winograd F(4,3)-along-x kernel (what the decoder's convolutions take on 64-pixel-tileable maps, ops.conv3x3(fast=True))
+    against float64 conv2d: the transforms cost ~4x the rounding error of the direct kernel -> 2e-5 * scale, as for F(2,3)."""
+    B, cins, Cout, H, W, act, nres = case
+    xs = [_cl(_rand((B, c, H, W), dev, 10 + k)) for k, c in enumerate(cins)]
+    w = _rand((Cout, sum(cins), 3, 3), dev, 20, 1.0 / np.sqrt(9 * sum(cins)))
+    b = _rand((Cout,), dev, 21)
+    res = [_cl(_rand((B, Cout, H, W), dev, 30 + k)) for k in range(nres)]
+    kw = dict(act=act, slope=0.1, res1=res[0] if nres > 0 else None, res2=res[1] if nres > 1 else None)
+    got = ops.conv3x3(xs, w, b, algo="winograd4", **kw)
+    want = _ref(xs, w, b, act, 0.1, res)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((got.double() - want).abs().max()) < tol
+    auto = ops.conv3x3(xs, w, b, fast=True, **kw)          # the automatic choice with fast=True is this kernel
+    assert torch.equal(auto, got)
+    plain = ops.conv3x3(xs, w, b, **kw)                    # ... and without it the F(2,3) kernel
+    assert float((plain.double() - want).abs().max()) < tol
+
+
 @pytest.mark.parametrize("B,H,W,act,norm", [(2, 40, 40, 1, True), (1, 37, 75, 2, False), (3, 8, 64, 0, True),
                                              (1, 131, 200, 1, True), (2, 5, 3, 1, False)])
 def test_conv3x3_rgb64_first_layer(ops, dev, B, H, W, act, norm):
