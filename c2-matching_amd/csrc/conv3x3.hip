@@ -32,6 +32,7 @@
 //
 // LDS: 2 x 26 KiB halo tiles + 3 x 8 KiB weight slots + 1 KiB = 77 KiB (MT = 2) -> two workgroups per CU: while one
 // waits at its barrier the other owns the matrix pipes.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -76,6 +77,7 @@ struct Params {
   float* mask_out;       // mode 3: [B][dg*9][H][W]
   const float* flow;     // mode 3: [B][fh][fw][2] (x, y) = index_to_flow of the arg-max map, or nullptr (no pre-offset)
   int fh, fw, scale, n_off;   // n_off = 2*dg*9 offset channels (the rest are mask logits)
+  int scale_shift;       // log2(scale): the head's pre-offset scales are powers of two (1, 2, 4 in C2-Matching)
   double* abs_sum;       // mode 3: C2M_ABS_SUM_SLOTS partial sums of |raw offset| or nullptr
   int out_vec4;          // mode 0: out / res pitches and bases are 16-byte aligned -> float4 stores
   int tpw;               // consecutive tiles per workgroup (>= 1)
@@ -130,39 +132,107 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 constexpr unsigned kOOB = 0x80000000u;   // voffset of a lane that must read zeros (>= any num_records used here)
 
 // DCN offset/mask head, one group of 4 consecutive head channels of one pixel (used by both convolution kernels).
-// Channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s: P_k[y][x] =
-// s * flow[(y - s*ki) / s][(x - s*kj) / s] (0 outside), channel order (y, x); mask = sigmoid.  `col` = channel inside this
-// launch's slice, v = conv + bias.  Returns the |raw offset| contribution for the reference's offset-mean warning.
-__device__ __forceinline__ float dcn_head_store(const Params& p, int b, int y, int x, int col, const f32x4& v) {
-  const size_t HWs = (size_t)p.H * p.W, pix = (size_t)y * p.W + x;
-  const int co = col + p.co_off;                // channel of the whole head
+// Channels (co, co+1) = (dy, dx) of (group, tap) gt = co/2; pre-offset of tap k at scale s = 2^sh: P_k[y][x] =
+// s * flow[(y - s*ki) >> sh][(x - s*kj) >> sh] (0 outside), channel order (y, x); mask = sigmoid.  `col` = channel inside
+// this launch's slice, v = conv + bias.  Returns the |raw offset| contribution for the reference's offset-mean warning.
+// Planar stores go through per-sample buffer resources: byte offset = channel * H*W*4 + pixel*4 as (per-lane VGPR part:
+// pixel + the lane's channel quad) + (wave-uniform SGPR part: the rest of the channel) -- no 64-bit arithmetic per store.
+struct HeadOut {
+  __amdgpu_buffer_rsrc_t off, msk;   // this sample's offset planes [n_off][H][W] / mask planes [nm][H][W]
+};
+__device__ __forceinline__ HeadOut head_out(const Params& p, int b) {
+  const unsigned HWb = (unsigned)(p.H * p.W) * 4u;
+  const int nm = p.cout_total - p.n_off;
+  HeadOut h;
+  h.off = make_rsrc(p.out + (size_t)b * p.n_off * p.H * p.W, (unsigned)p.n_off * HWb);
+  h.msk = make_rsrc(p.mask_out + (size_t)b * nm * p.H * p.W, (unsigned)nm * HWb);
+  return h;
+}
+// col_u: wave-uniform part of the slice channel (multiple of 8), lane_q = 4 * hi: the lane's quad inside it
+__device__ __forceinline__ float dcn_head_store(const Params& p, const HeadOut& ho, int b, int y, int x, int col_u, int lane_q,
+                                                const f32x4& v) {
+  const int HWb = p.H * p.W * 4;
+  const int co_u = col_u + p.co_off;            // uniform part of the head channel
+  const int co = co_u + lane_q;
+  const int pixb = (y * p.W + x) * 4;
   float asum = 0.0f;
-  if (co < p.n_off) {
+  const int vo = pixb + lane_q * HWb;
+  if (co_u < p.n_off) {   // wave-uniform: n_off is a multiple of 8, so both channel quads of co_u lie on the same side
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int gt = (co >> 1) + h2, tap = gt % 9;
-      const int ki = tap / 3, kj = tap - 3 * ki;
+      const int ki = (tap * 11) >> 5, kj = tap - 3 * ki;   // tap / 3 for tap < 9
       float fy = 0.0f, fx = 0.0f;
       if (p.flow) {
-        const int ys = y - p.scale * ki, xs = x - p.scale * kj;
-        if (ys >= 0 && xs >= 0) {
-          const int yy = ys / p.scale, xx = xs / p.scale;
-          if (yy < p.fh && xx < p.fw) {
-            const float2 f = reinterpret_cast<const float2*>(p.flow)[((size_t)b * p.fh + yy) * p.fw + xx];
-            fx = f.x * (float)p.scale;
-            fy = f.y * (float)p.scale;
-          }
-        }
+        // branch-free: an out-of-range tap reads flow entry (0, 0) of the sample and is multiplied by 0
+        const int ys = y - (ki << p.scale_shift), xs = x - (kj << p.scale_shift);
+        const int yy = ys >> p.scale_shift, xx = xs >> p.scale_shift;
+        const bool ok = (ys >= 0) & (xs >= 0) & (yy < p.fh) & (xx < p.fw);
+        const float2 f = reinterpret_cast<const float2*>(p.flow)[(size_t)b * p.fh * p.fw + (ok ? yy * p.fw + xx : 0)];
+        const float sc = ok ? (float)p.scale : 0.0f;
+        fx = f.x * sc;
+        fy = f.y * sc;
       }
       asum += fabsf(v[2 * h2]) + fabsf(v[2 * h2 + 1]);
-      p.out[((size_t)b * p.n_off + co + 2 * h2) * HWs + pix] = v[2 * h2] + fy;
-      p.out[((size_t)b * p.n_off + co + 2 * h2 + 1) * HWs + pix] = v[2 * h2 + 1] + fx;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2 * h2] + fy), ho.off, vo, (co_u + 2 * h2) * HWb, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2 * h2 + 1] + fx), ho.off, vo,
+                                            (co_u + 2 * h2 + 1) * HWb, 0);
     }
   } else {
-    const int nm = p.cout_total - p.n_off;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (col + e < p.Cout) p.mask_out[((size_t)b * nm + (co - p.n_off) + e) * HWs + pix] = 1.0f / (1.0f + expf(-v[e]));
+      if (col_u + lane_q + e < p.Cout)
+        // sigmoid with the hardware exp2 / reciprocal (1 ulp each): the mask is a multiplier of sampled features in a
+        // tolerance-based path; the correctly rounded expf + division cost ~20 instructions per value, at every call site
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]))), ho.msk, vo,
+                                              (co_u - p.n_off + e) * HWb, 0);
+  }
+  return asum;
+}
+
+// Two horizontally adjacent pixels (x even) at once, for the Winograd kernel whose lanes own pixel pairs: one 8-byte store
+// per channel, so a wave writes whole 128-byte lines of every plane (dword stores at an 8-byte lane stride left every line
+// half written per instruction -- the 5.7 GB the large head writes made that its bottleneck).
+__device__ __forceinline__ float dcn_head_store2(const Params& p, const HeadOut& ho, int b, int y, int x, int col_u, int lane_q,
+                                                 const f32x4& v0, const f32x4& v1) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int HWb = p.H * p.W * 4;
+  const int co_u = col_u + p.co_off;
+  const int co = co_u + lane_q;
+  const int vo = (y * p.W + x) * 4 + lane_q * HWb;
+  float asum = 0.0f;
+  auto st2 = [&](const __amdgpu_buffer_rsrc_t& rs, float a, float c, int so) __attribute__((always_inline)) {
+    const u32x2 d = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c)};
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, vo, so, 0);
+  };
+  if (co_u < p.n_off) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int gt = (co >> 1) + h2, tap = gt % 9;
+      const int ki = (tap * 11) >> 5, kj = tap - 3 * ki;
+      float fy[2] = {0.0f, 0.0f}, fx[2] = {0.0f, 0.0f};
+      if (p.flow) {
+        const int ys = y - (ki << p.scale_shift), yy = ys >> p.scale_shift;
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int xs = x + px - (kj << p.scale_shift), xx = xs >> p.scale_shift;
+          const bool ok = (ys >= 0) & (xs >= 0) & (yy < p.fh) & (xx < p.fw);
+          const float2 f = reinterpret_cast<const float2*>(p.flow)[(size_t)b * p.fh * p.fw + (ok ? yy * p.fw + xx : 0)];
+          const float sc = ok ? (float)p.scale : 0.0f;
+          fx[px] = f.x * sc;
+          fy[px] = f.y * sc;
+        }
+      }
+      asum += (fabsf(v0[2 * h2]) + fabsf(v0[2 * h2 + 1])) + (fabsf(v1[2 * h2]) + fabsf(v1[2 * h2 + 1]));
+      st2(ho.off, v0[2 * h2] + fy[0], v1[2 * h2] + fy[1], (co_u + 2 * h2) * HWb);
+      st2(ho.off, v0[2 * h2 + 1] + fx[0], v1[2 * h2 + 1] + fx[1], (co_u + 2 * h2 + 1) * HWb);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col_u + lane_q + e < p.Cout)
+        st2(ho.msk, __builtin_amdgcn_rcpf(1.0f + __expf(-v0[e])), __builtin_amdgcn_rcpf(1.0f + __expf(-v1[e])),
+            (co_u - p.n_off + e) * HWb);
   }
   return asum;
 }
@@ -427,6 +497,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
     // ----------------------------------------------------------------------------------------------------------------
     if constexpr (MODE == 3) {
       float asum = 0.0f;
+      const HeadOut ho = head_out(p, b);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -436,7 +507,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * qd + e];
-          asum += dcn_head_store(p, b, y, x, col, v);
+          asum += dcn_head_store(p, ho, b, y, x, col - 4 * hi, 4 * hi, v);
         }
       if (p.abs_sum) {
 #pragma unroll
@@ -810,6 +881,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     const float* r2 = p.res2 ? p.res2 + opix + co_lane : nullptr;
     float* ob = p.out + opix + co_lane;
     float asum = 0.0f;
+    HeadOut ho;
+    if constexpr (MODE == 3) ho = head_out(p, b);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -830,8 +903,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
         }
         if constexpr (MODE == 3) {
           if (pok && co < p.Cout) {
-            asum += dcn_head_store(p, b, y, x, co, y0v);
-            asum += dcn_head_store(p, b, y, x + 1, co, y1v);
+            asum += dcn_head_store2(p, ho, b, y, x, co - 4 * hi, 4 * hi, y0v, y1v);
           }
         } else if (pok && co + 3 < p.Cout) {
           const int o = mt * 32 + 8 * qd;
@@ -1497,6 +1569,11 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.out_pix_pitch = d->out_pix_pitch; p.out_row_pitch = d->out_row_pitch; p.out_img_pitch = d->out_img_pitch;
   p.res1 = d->res1; p.res2 = d->res2; p.mask_out = d->mask_out; p.flow = d->flow; p.fh = d->fh; p.fw = d->fw;
   p.scale = d->scale; p.n_off = d->n_off; p.abs_sum = d->abs_sum;
+  p.scale_shift = -1;
+  for (int sh = 0; sh < 16; ++sh)
+    if (d->scale == (1 << sh)) p.scale_shift = sh;
+  if (d->out_mode == 3 && d->flow && p.scale_shift < 0) return C2M_ERR_UNSUPPORTED;   // pre-offset scales are powers of two
+  if (d->out_mode == 3 && (long long)cout_total * d->H * d->W * 4 >= 0x7fffffffLL) return C2M_ERR_UNSUPPORTED;   // 32-bit plane offsets
   p.out_vec4 = out_vec4 ? 1 : 0;
   p.co_off = d->out_mode == 3 ? d->cout_offset : 0;
   p.cout_total = cout_total;
@@ -1544,7 +1621,13 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   if (wino4) {
     static unsigned long long done_w4 = 0;
     const size_t lds4 = 2 * conv::wino4::IN_BYTES + conv::wino4::NRING * conv::wino4::WUNIT + 1024 + 256;
-    static const int abl = [] { const char* e = getenv("C2M_CONV_ABL"); return e ? atoi(e) : 0; }();
+    // C2M_CONV_ABL = 1..3: timing-only ablations of the F(4,3) kernel (see its template parameter); results are WRONG
+    static const int abl = [] {
+      const char* e = getenv("C2M_CONV_ABL");
+      const int v = e ? atoi(e) : 0;
+      if (v > 0) fprintf(stderr, "c2m: C2M_CONV_ABL=%d -- conv3x3 F(4,3) runs a timing-only ablation, its results are wrong\n", v);
+      return v;
+    }();
     static unsigned long long done_abl[4] = {};
     auto go4 = [&](auto kern, unsigned long long& dn) {
       if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds4, dn)) == C2M_OK)
