@@ -259,8 +259,8 @@ _WINO4 = _os.environ.get("C2M_CONV_WINO4", "1") != "0"
 
 
 def _wino_ok(srcs, weight, out_mode, W):
-    """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 64- (or 32-) pixel tiles along x."""
-    return (_WINO and out_mode == "nhwc" and weight.shape[0] % 64 == 0 and W % 32 == 0 and
+    """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 32-pixel tiles along x."""
+    return (_WINO and out_mode in ("nhwc", "nhwc_pool2") and weight.shape[0] % 64 == 0 and W % 32 == 0 and
             all(s.shape[1] % 16 == 0 for s in srcs) and sum(s.shape[1] for s in srcs) == weight.shape[1])
 
 
@@ -275,7 +275,8 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
 
     srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
     the (zero-padded) weight is not accepted -- pad the tensor).  out_mode: "nhwc" -> channels_last [B,Cout,H,W];
-    "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous.
+    "pixel_shuffle" -> channels_last [B,Cout/4,2H,2W] (= PixelShuffle(2) of the conv output); "nchw" -> contiguous;
+    "nhwc_pool2" -> channels_last [B,Cout,H/2,W/2] = MaxPool2d(2, 2) of the activated output (Winograd F(2,3) shapes only).
     out2_grouped8: a zero-bordered group-major buffer [B,Cout/8,H+3,W+3,8] that receives a second copy of the output
     (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only.
     algo: None (auto: Winograd F(2,3) where the shapes allow, else direct), "direct", "winograd", "winograd4".  fast=True lets
@@ -324,6 +325,13 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     elif out_mode == "pixel_shuffle":
         out = empty_nhwc(B, Cout // 4, 2 * H, 2 * W, dev)
         d.out_mode = 1
+        o = _nhwc_src(out, "out")
+        d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
+    elif out_mode == "nhwc_pool2":
+        if wino != 1 or H % 2 != 0 or W % 2 != 0:
+            raise _lib.C2MError("conv3x3: the pooled epilogue needs the Winograd F(2,3) kernel and even H, W")
+        out = empty_nhwc(B, Cout, H // 2, W // 2, dev)
+        d.out_mode = 4
         o = _nhwc_src(out, "out")
         d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
     elif out_mode == "nchw":
@@ -559,6 +567,11 @@ def bordered_of(t):
     return getattr(t, "_c2m_bordered", None)
 
 
+def _pool_is_2x2(m):
+    two = lambda v: v in (2, (2, 2))   # noqa: E731
+    return two(m.kernel_size) and two(m.stride) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) and not m.ceil_mode
+
+
 def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, grouped8_taps=()):
     """Run an ordered {name: nn.Conv2d(3x3, pad 1) | nn.ReLU | nn.MaxPool2d(2, 2)} stack (torchvision's vgg `features`
     layout, mmsr/models/archs/vgg_arch.py:107-123) on the fused channels-last convolution: every conv + its ReLU is one
@@ -600,6 +613,9 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
                 raise _lib.C2MError("tapping a conv output that is followed by an in-place ReLU is not supported")
             last = (k + (2 if relu else 1)) >= len(names)
             Bc, _, Hc, Wc = cur.shape
+            nxt = layers[names[k + 2]] if (relu and k + 2 < len(names)) else None
+            pool = (isinstance(nxt, torch.nn.MaxPool2d) and _pool_is_2x2(nxt) and tap_name is None and not (k == 0 and rgb64) and
+                    Hc % 2 == 0 and Wc % 2 == 0 and _wino_ok([cur], layer.weight, "nhwc_pool2", Wc))
             if last and last_nchw:
                 cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out_mode="nchw")
                 out[names[k + 1] if relu else name] = cur
@@ -610,6 +626,9 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
                 view._c2m_bordered = bo
                 out[tap_name] = view
                 cur = view
+            elif pool:   # conv -> ReLU -> MaxPool2d(2, 2) in one launch: only the pooled map is written
+                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU, out_mode="nhwc_pool2")
+                k += 1   # (the pool layer)
             else:
                 cur = conv(k, cur, layer, act=ACT_RELU if relu else ACT_NONE)
             k += 2 if relu else 1

@@ -654,7 +654,9 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_wino_kernel(const float*
 
 // PX = pixel pairs per wave row: 16 -> workgroup tile 32 x 8 pixels (wave = two rows of 16 pairs; what the launcher uses:
 // smaller halo), 32 -> 64 x 4 (wave = one row; not instantiated any more, see c2m_conv3x3_nhwc_f32)
-template <int PX, int MODE>   // MODE 0: channels-last (+ activation, residuals); MODE 3: DCN offset/mask head
+// MODE 0: channels-last (+ activation, residuals); MODE 3: DCN offset/mask head; MODE 4: channels-last + activation +
+// MaxPool2d(2, 2) (the conv1_2 / conv2_2 -> pool steps of the VGG towers: only the pooled map is written)
+template <int PX, int MODE>
 __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   constexpr int RW = 32 / PX;                      // pixel rows per wave
   constexpr int TWX = 2 * PX, THY = 4 * RW;        // pixel tile of a workgroup
@@ -895,7 +897,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
           const float m0 = M[0][mt][4 * qd + e], m1 = M[1][mt][4 * qd + e], m2 = M[2][mt][4 * qd + e], m3 = M[3][mt][4 * qd + e];
           y0v[e] = ((m0 + m1) + m2) + bv[e];
           y1v[e] = ((m1 - m2) - m3) + bv[e];
-          if constexpr (MODE == 0) {
+          if constexpr (MODE == 0 || MODE == 4) {
             if (p.act == 1) { y0v[e] = fmaxf(y0v[e], 0.0f); y1v[e] = fmaxf(y1v[e], 0.0f); }
             else if (p.act == 2) { y0v[e] = fmaxf(y0v[e], y0v[e] * p.slope); y1v[e] = fmaxf(y1v[e], y1v[e] * p.slope); }
           }
@@ -905,6 +907,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
           if (pok && co < p.Cout) {
             asum += dcn_head_store2(p, ho, b, y, x, co - 4 * hi, 4 * hi, y0v, y1v);
           }
+        } else if constexpr (MODE == 4) {
+          // horizontal max inside the lane (its pixel pair), vertical max with the lane 16 further on (rows 2 wv, 2 wv + 1 of
+          // the wave: PX == 16); the even-row lanes store pooled pixel (y / 2, x / 2)
+          static_assert(MODE != 4 || PX == 16, "the pooled epilogue pairs the two rows of a wave");
+          f32x4 pv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hm = fmaxf(y0v[e], y1v[e]);
+            pv[e] = fmaxf(hm, __shfl_xor(hm, 16, 64));
+          }
+          if (pok && (j & 16) == 0 && co + 3 < p.Cout)
+            *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.out_img_pitch + (size_t)(y >> 1) * p.out_row_pitch +
+                                      (size_t)(x >> 1) * p.out_pix_pitch + co_lane + mt * 32 + 8 * qd) = pv;
         } else if (pok && co + 3 < p.Cout) {
           const int o = mt * 32 + 8 * qd;
           if (r1) { y0v += *reinterpret_cast<const f32x4*>(r1 + o); y1v += *reinterpret_cast<const f32x4*>(r1 + p.out_pix_pitch + o); }
@@ -1528,7 +1543,8 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   const bool wino4 = d->algo == C2M_CONV_WINOGRAD_F43X;
   const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X || wino4;   // both: 16-channel chunks, 64-cout blocks
   if (d->algo != 0 && !wino) return C2M_ERR_INVALID_ARG;
-  if (wino && ((d->out_mode != 0 && d->out_mode != 3) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
+  if (wino && ((d->out_mode != 0 && d->out_mode != 3 && d->out_mode != 4) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
+  if (d->out_mode == 4 && (d->algo != C2M_CONV_WINOGRAD_F23X || d->H % 2 != 0 || d->res1 || d->res2 || d->out2)) return C2M_ERR_UNSUPPORTED;
   if (wino4 && (d->out_mode != 0 || d->W % 64 != 0)) return C2M_ERR_UNSUPPORTED;
   const int kch = wino ? conv::wino::KC : conv::KCH;
   int csum = 0;
@@ -1539,7 +1555,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     csum += d->src[s].C;
   }
   if (csum != d->Cin || d->H >= 32768 || d->W >= 65536) return C2M_ERR_INVALID_ARG;
-  if (d->out_mode < 0 || d->out_mode > 3) return C2M_ERR_INVALID_ARG;
+  if (d->out_mode < 0 || d->out_mode > 4) return C2M_ERR_INVALID_ARG;
   const bool out_vec4 = !(d->out_pix_pitch % 4 != 0 || d->out_row_pitch % 4 != 0 || d->out_img_pitch % 4 != 0 ||
                           ((uintptr_t)d->out & 15) || ((uintptr_t)d->res1 & 15) || ((uintptr_t)d->res2 & 15));
   if (d->out_mode == 1 && d->Cout % 4 != 0) return C2M_ERR_INVALID_ARG;
@@ -1585,7 +1601,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
 
   const int MW = wino ? 64 : conv_mw(d->Cout);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
-  if (wino && d->out_mode == 0 && !out_vec4) return C2M_ERR_UNSUPPORTED;
+  if (wino && (d->out_mode == 0 || d->out_mode == 4) && !out_vec4) return C2M_ERR_UNSUPPORTED;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
   if (d->act == C2M_ACT_LEAKY_RELU && !(d->slope >= 0.0f && d->slope <= 1.0f)) return C2M_ERR_UNSUPPORTED;   // max(v, slope*v)
   for (int sidx = 0; sidx < d->nsrc; ++sidx) {   // 32-bit byte offsets inside one sample (buffer addressing)
@@ -1646,8 +1662,11 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
       if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsw, dn)) != C2M_OK) return;
       hipLaunchKernelGGL(kern, grid, dim3(256), ldsw, st, p);
     };
+    static unsigned long long done_pool = 0;
     if (d->out_mode == 3) {
       gow(&conv::conv3x3_wino_kernel<16, 3>, done_w[1][1]);
+    } else if (d->out_mode == 4) {
+      gow(&conv::conv3x3_wino_kernel<16, 4>, done_pool);
     } else {
       gow(&conv::conv3x3_wino_kernel<16, 0>, done_w[1][0]);
     }

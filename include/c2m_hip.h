@@ -193,7 +193,7 @@ typedef struct c2m_conv_src {
 } c2m_conv_src;
 
 enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2 };
-enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3 };
+enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3, C2M_OUT_NHWC_MAXPOOL2 = 4 };
 
 typedef struct c2m_conv3x3_desc {
   int B, H, W, Cin, Cout;
@@ -205,6 +205,8 @@ typedef struct c2m_conv3x3_desc {
   float slope;             /* LeakyReLU negative slope */
   int out_mode;            /* C2M_OUT_* */
   float* out;              /* NHWC: pitches below.  PIXEL_SHUFFLE2: [B][2H][2W][Cout/4] with the pitches below.
+                              NHWC_MAXPOOL2: [B][H/2][W/2][Cout] = MaxPool2d(2,2) of the activated output (C2M_CONV_WINOGRAD_F23X
+                              only, even H; the conv -> ReLU -> pool steps of the VGG towers, vgg_arch.py:107-123).
                               NCHW: [B][Cout][H][W].  DCN_HEAD: offset [B][n_off][H][W] (raw + pre-offset, (dy,dx) pairs) */
   int out_pix_pitch, out_row_pitch;
   long long out_img_pitch;

@@ -9,6 +9,8 @@ timeout 1800 python -m pytest tests -m gpu -q -rA 2>&1 | tail -90 > $O/pytest_gp
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; echo "rc=$?" >> $O/bench_default.log
 timeout 300 python bench.py --workload corr --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_corr.log 2>&1
 timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1
+echo "--- with fast=True (the decoder's setting: Winograd F(4,3) where the map is a multiple of 64 pixels wide)" >> $O/bench_conv.log
+timeout 300 python scripts/bench_conv.py --fast --only "64 @" >> $O/bench_conv.log 2>&1
 timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1
 timeout 600 python scripts/bench_train.py > $O/bench_train.log 2>&1
 cd /tmp
@@ -18,5 +20,5 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o 
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/pmc_write.log 2>&1
 cd $R
 for f in $(find gpurun_out/final -name "*.db"); do rm -f $f; done
-# the per-dispatch traces are large: keep only the stats / counter CSVs
+# the per-dispatch traces are large: keep only the stats / counter CSVs; then: python scripts/summarize_step.py r02_final 4
 find gpurun_out/final -name "*kernel_trace.csv" -size +8M -delete

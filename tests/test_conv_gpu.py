@@ -193,6 +193,21 @@ def test_vgg_and_extractor_stacks_match_stock_torch(dev):
         assert err < 2e-4 * max(1.0, float(want_e[k].abs().max())), (k, err)
 
 
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 64, 12, 64), (1, 128, 128, 22, 96), (1, 64, 128, 8, 32)])
+def test_conv3x3_fused_maxpool(ops, dev, B, C, Co, H, W):
+    """conv + ReLU + MaxPool2d(2, 2) in the Winograd F(2,3) kernel's epilogue (the conv1_2 / conv2_2 -> pool steps of the VGG
+    towers): identical to pooling the un-fused kernel's output (max is exact), and within conv tolerance of float64."""
+    x = _cl(_rand((B, C, H, W), dev, 70))
+    w = _rand((Co, C, 3, 3), dev, 71, 1.0 / np.sqrt(9 * C))
+    b = _rand((Co,), dev, 72)
+    got = ops.conv3x3(x, w, b, act=ops.ACT_RELU, out_mode="nhwc_pool2")
+    plain = ops.conv3x3(x, w, b, act=ops.ACT_RELU, algo="winograd")
+    assert got.shape == (B, Co, H // 2, W // 2) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, F.max_pool2d(plain, 2, 2))
+    want = F.max_pool2d(_ref([x], w, b, 1, 0.0, []), 2, 2)
+    assert float((got.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
 WINO4_CASES = [
     # B, [Cin per source], Cout, H, W, act, n residuals     (W % 64 == 0, Cout % 64 == 0, channels % 16 == 0)
     (2, [64], 64, 12, 64, 1, 0),
