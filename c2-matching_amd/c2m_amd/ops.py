@@ -200,17 +200,35 @@ def conv_flops_of_last_steps(reset=True, executed=False):
 
 class _WeightCache:
     """Re-laid-out conv weights, keyed by the parameter tensor and its version counter: inference re-uses them across
-    calls; an optimiser step (in-place update -> new _version) or load_state_dict invalidates them."""
+    calls; an optimiser step (in-place update -> new _version) or load_state_dict invalidates them.  An entry belongs to
+    one tensor OBJECT (weak reference): a new parameter that happens to reuse a dead one's id, address and version never
+    hits its entry, and entries die with their tensor."""
 
     def __init__(self):
         self._d = {}
 
+    def _lookup(self, slot, key, weight):
+        hit = self._d.get(slot)
+        if hit is not None and hit[0] == key and hit[2]() is weight:
+            return hit[1]
+        return None
+
+    def _store(self, slot, key, weight, value):
+        import weakref
+        d = self._d
+
+        def _drop(ref, slot=slot):
+            cur = d.get(slot)
+            if cur is not None and cur[2] is ref:
+                del d[slot]
+        self._d[slot] = (key, value, weakref.ref(weight, _drop))
+
     def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3) layout
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
         slot = (id(weight), rows, wino)
-        hit = self._d.get(slot)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        hit = self._lookup(slot, key, weight)
+        if hit is not None:
+            return hit
         w = weight.detach()
         if rows is not None:
             w = w[rows[0]:rows[1]]
@@ -231,7 +249,7 @@ class _WeightCache:
         with torch.cuda.device(w.device):
             fn = (L.c2m_conv3x3_relayout_f32, L.c2m_conv3x3_relayout_wino_f32, L.c2m_conv3x3_relayout_wino4_f32)[wino]
             _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
-        self._d[slot] = (key, wr)
+        self._store(slot, key, weight, wr)
         return wr
 
 
@@ -486,9 +504,9 @@ class BorderedNHWC:
 class _DcnWeightCache(_WeightCache):
     def get(self, weight, dg):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), dg, weight.device.index)
-        hit = self._d.get(id(weight))
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        hit = self._lookup(id(weight), key, weight)
+        if hit is not None:
+            return hit
         w = _dev_f32(weight.detach(), "weight")
         Co, C, kh, kw = w.shape
         L = _lib.lib()
@@ -498,7 +516,7 @@ class _DcnWeightCache(_WeightCache):
         wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(L.c2m_dcn_v2_relayout_f32(_stream(), w.data_ptr(), C, Co, kh, kw, dg, wt.data_ptr()), "c2m_dcn_v2_relayout_f32")
-        self._d[id(weight)] = (key, wt)
+        self._store(id(weight), key, weight, wt)
         return wt
 
 

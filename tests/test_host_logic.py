@@ -245,3 +245,21 @@ def test_distributed_validation_equals_single_process():
         for k in ('psnr', 'psnr_y', 'ssim_y'):
             assert abs(out[2][r][k] - single[k]) < 1e-9, (r, k)
         assert out[2][r]['count'] == 5
+
+
+def test_weight_cache_entries_belong_to_one_tensor_object():
+    """ops._WeightCache: an entry is only ever returned for the tensor object it was made for (a new parameter that reuses
+    a dead one's id / address / version must not inherit its re-laid-out weights) and it dies with that tensor."""
+    import gc
+    import torch
+    from c2m_amd import ops
+    c = ops._WeightCache()
+    w = torch.nn.Parameter(torch.zeros(2, 2, 3, 3))
+    c._store(("slot",), ("key",), w, "relayout-of-w")
+    assert c._lookup(("slot",), ("key",), w) == "relayout-of-w"
+    assert c._lookup(("slot",), ("other key",), w) is None            # version / address changed
+    twin = torch.nn.Parameter(torch.zeros(2, 2, 3, 3))
+    assert c._lookup(("slot",), ("key",), twin) is None               # same key, different object
+    del w
+    gc.collect()
+    assert len(c._d) == 0
