@@ -905,8 +905,11 @@ __global__ void __launch_bounds__(256) dcn_bwd_offmask_kernel(const float* __res
       const float ah = __builtin_amdgcn_fmed3f(ar, -1.0f, Hf), aw = __builtin_amdgcn_fmed3f(ac, -1.0f, Wf);
       const float fh = floorf(ah), fw = floorf(aw);
       lh[lg] = ah - fh; lw[lg] = aw - fw; hh[lg] = 1.0f - lh[lg]; hw[lg] = 1.0f - lw[lg];
-      const unsigned o1 = (unsigned)(((int)fh * Wp + (int)fw + Wp + 1) * g.C + grp * CPG + (CPG == 32 ? 16 * hi : 0));
-      const unsigned o2 = o1 + (unsigned)g.C, o3 = o1 + (unsigned)(Wp * g.C), o4 = o3 + (unsigned)g.C;
+      // channels-last, or (8-channel groups, Geom::in_grouped) the group-major copy: see dcn_fwd_nhwc_kernel
+      const unsigned pixs = g.in_grouped ? (unsigned)CPG : (unsigned)g.C;
+      const unsigned gbase = g.in_grouped ? (unsigned)(grp * (g.H + 3) * Wp * CPG) : (unsigned)(grp * CPG);
+      const unsigned o1 = (unsigned)((int)fh * Wp + (int)fw + Wp + 1) * pixs + gbase + (CPG == 32 ? 16 * hi : 0);
+      const unsigned o2 = o1 + pixs, o3 = o1 + (unsigned)Wp * pixs, o4 = o3 + pixs;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         v[lg][0][q] = *reinterpret_cast<const f32x4*>(in_b + o1 + 4 * q);
@@ -1047,14 +1050,16 @@ __global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(const float* __rest
       const float lh = ah - fh, lw = aw - fw, hw = 1.0f - lw;
       const float mh = (1.0f - lh) * mk, ml = lh * mk;
       w1 = mh * hw; w2 = mh * lw; w3 = ml * hw; w4 = ml * lw;
-      const float* s1 = in_b + (size_t)(((int)fh * Wp + (int)fw + Wp + 1) * g.C + grp * g.CPG + cig0);
-      const float* s3 = s1 + Wp * g.C;
+      const int pixs = g.in_grouped ? g.CPG : g.C;   // floats between horizontally adjacent positions
+      const int gbase = g.in_grouped ? grp * (g.H + 3) * Wp * g.CPG : grp * g.CPG;
+      const float* s1 = in_b + (size_t)(((int)fh * Wp + (int)fw + Wp + 1) * pixs + gbase + cig0);
+      const float* s3 = s1 + Wp * pixs;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         cv[0][q] = *reinterpret_cast<const f32x4*>(s1 + 4 * q);
-        cv[1][q] = *reinterpret_cast<const f32x4*>(s1 + g.C + 4 * q);
+        cv[1][q] = *reinterpret_cast<const f32x4*>(s1 + pixs + 4 * q);
         cv[2][q] = *reinterpret_cast<const f32x4*>(s3 + 4 * q);
-        cv[3][q] = *reinterpret_cast<const f32x4*>(s3 + g.C + 4 * q);
+        cv[3][q] = *reinterpret_cast<const f32x4*>(s3 + pixs + 4 * q);
       }
     };
     if (split < total) fetch(split);
@@ -1590,7 +1595,10 @@ extern "C" int c2m_dcn_v2_backward_f32(c2m_stream_t stream, const float* input, 
   if ((rc = check_launch()) != C2M_OK) return rc;
   // zero-bordered channels-last copy of the input for the gathers of the offset/mask and weight kernels
   float* inl = ws.nhwc ? reinterpret_cast<float*>(static_cast<char*>(workspace) + ws.inl) : nullptr;
-  if (inl) launch_nhwc_copy(st, input, B, C, H, W, inl);
+  // (8-channel groups: group-major, as in the forward -- a 32-byte sample run then shares its line with its neighbours)
+  const bool bgrouped = inl && g.CPG == 8 && [] { const char* e = getenv("C2M_DCN_BWD_GROUPED"); return !(e && e[0] == '0'); }();
+  g.in_grouped = bgrouped ? 1 : 0;
+  if (inl) launch_nhwc_copy(st, input, B, C, H, W, inl, bgrouped);
   if (offmask) {
     ProfileScope prof(C2M_KERNEL_DCN_BWD_DATA, st);
     const int nkt = g.KtotPad / 32;
