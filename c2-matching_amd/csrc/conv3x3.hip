@@ -32,6 +32,15 @@
 //
 // LDS: 2 x 26 KiB halo tiles + 3 x 8 KiB weight slots + 1 KiB = 77 KiB (MT = 2) -> two workgroups per CU: while one
 // waits at its barrier the other owns the matrix pipes.
+//
+// Kernels in this file (DESIGN.md 6 has the measurements):
+//   conv3x3_kernel<MT, MODE>        the direct kernel described above (any shape the family supports);
+//   conv3x3_wino_kernel<PX, MODE>   Winograd F(2,3) along x, 1.5x fewer MFMAs: channels-last outputs with 64-channel tiles
+//                                   on maps a multiple of 32 pixels wide; MODE 3 = DCN head, MODE 4 = + ReLU + MaxPool2d(2,2);
+//   conv3x3_wino4_kernel            Winograd F(4,3) along x, 2x fewer MFMAs, one wave per SIMD; decoder only (its rounding
+//                                   error is ~4x the direct kernel's), maps a multiple of 64 pixels wide;
+//   conv3x3_c3_kernel               the 3 -> 64 first layer of the image towers (im2col, K = 27, fused (x - mean) / std);
+//   *_relayout_*_kernel, index_to_flow_kernel   weight images for the three algorithms; arg-max indices -> flow map.
 #include <stdio.h>
 #include <stdlib.h>
 

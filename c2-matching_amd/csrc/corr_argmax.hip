@@ -25,7 +25,10 @@
 //     Every non-MFMA instruction costs matrix time on this chip (scripts/ubench/issue_cost.hip), hence 3 LDS reads,
 //     3 plain VALU ops, 1 compare and 2 selects per candidate;
 //   * after the sweep a 32-lane shuffle reduction with the (larger value, then lower index) rule yields the
-//     reference's "first maximum" semantics exactly, independent of the visiting order.
+//     reference's "first maximum" semantics exactly, independent of the visiting order;
+//   * ref pixel rows that repeat the three rows above them bit for bit (the band a zero-padded Ref leaves,
+//     ref_cufed_dataset.py:99-114) are not swept: their patches can only tie with an earlier, lower-index patch
+//     (ref_row_equal_kernel / ref_row_run_kernel build the per-(sample, x-tile) skip table).
 //
 // LDS: ring 3*256*32*4 = 96 KiB + row buffers 2*C*32*4 = 64 KiB (C=256) = all 160 KiB of a CU; 1 workgroup per CU,
 // 2 waves per SIMD.  Roofline: MFMA (fp32 matrix peak 157.3 TF); HBM traffic is a few times the compulsory 53 MB/pair

@@ -11,7 +11,10 @@
 //                  buffer; bias in the epilogue (the reference spends a rank-1 GEMM on it).
 //                  dcn_fwd_nhwc_kernel (8/16/32 channels per group, even group count): gathers from a zero-bordered
 //                  channels-last copy of the input (float4 per 4 channels, no validity logic), weights DMA'd to LDS in
-//                  chunks, two-deep gather pipeline, 8 x 4 pixel patch per wave; optional bf16-MFMA variant.
+//                  chunks, two-deep gather pipeline, 8 x 4 pixel patch per wave; optional bf16-MFMA variant.  8-channel
+//                  groups gather from a GROUP-MAJOR copy [dg][H+3][W+3][8] instead (Geom::in_grouped; forward and both
+//                  channels-last backward kernels): a 32-byte sample run then shares its cache line with the neighbouring
+//                  positions of its group instead of with three other groups -- the kernels wait on line look-ups.
 //                  dcn_fwd_mfma_kernel: any other geometry, gathers from NCHW, weights from L1/L2.
 //   backward data  dCol tile = W^T . gO on MFMA (gO kept in registers as the B operand), consumed in place.
 //                  dcn_bwd_offmask_kernel (grad_input not requested): channels-last gathers, Wb tile in LDS, every lane
