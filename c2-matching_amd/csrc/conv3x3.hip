@@ -1028,6 +1028,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
   // [in0 | in1 | w ring x3 | dummy 1 KiB | bias 64 floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const unsigned in_base = lds0, w_base = lds0 + 2 * IN_BYTES, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
+  // With one wave per SIMD every VALU instruction is paid for in matrix time, so all per-lane address arithmetic that does
+  // not depend on the tile is done once: the 16-byte pieces of a halo pixel are swizzled by its COLUMN ((x >> 2) & 3, not
+  // by the linear pixel index), which makes a raw read address linear in the row tap (immediate offsets) and in the
+  // buffer (one add per chunk), and the DMA slots' (row, column, piece) are constants of the lane.
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1062,18 +1066,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
   unsigned ivoff[NIN_W];
   int ib = 0, iy0 = 0, ix0 = 0;
   __amdgpu_buffer_rsrc_t rs0, rs1;
-  const int qdma = (l & 3) ^ ((l >> 4) & 3);
+  // DMA slot sl of this lane: halo pixel pl = 16 (wv + 4 sl) + (l >> 2) = (row ry, column rx), LDS slot l & 3 holds logical
+  // piece (l & 3) ^ ((rx >> 2) & 3).  Packed: ry | rx << 8 | piece << 16 | valid << 24.
+  int slotc[NIN_W];
+#pragma unroll
+  for (int sl = 0; sl < NIN_W; ++sl) {
+    const int n = wv + 4 * sl, pl = 16 * n + (l >> 2);
+    const int ry = pl / HWc, rx = pl - ry * HWc;
+    slotc[sl] = ry | (rx << 8) | ((((l & 3) ^ ((rx >> 2) & 3))) << 16) | ((n < NIN_REAL && ry < HHr) ? (1 << 24) : 0);
+  }
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
-    const int pl0 = 16 * wv + (l >> 2);
-    int ry = pl0 / HWc, rx = pl0 - ry * HWc;
 #pragma unroll
     for (int sl = 0; sl < NIN_W; ++sl) {
-      const int n = wv + 4 * sl;
-      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-      const bool ok = n < NIN_REAL && ry < HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * qdma) * 4u : kOOB;
-      rx += 64;
-      if (rx >= HWc) { rx -= HWc; ry += 1; }
+      const int c = slotc[sl];
+      const int iy = iy0 - 1 + (c & 0xff), ix = ix0 - 1 + ((c >> 8) & 0xff);
+      const bool ok = (c >> 24) != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * ((c >> 16) & 3)) * 4u : kOOB;
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
@@ -1144,15 +1152,34 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
   };
   // input transform of one row tap: six raw b128 reads per k-quad (input columns 4t-1 .. 4t+4 of the lane's quad)
   f32x4 V[6][2], d[2][6];
-  auto issue_raw = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
+  // raw read addresses of row tap 0 in the CURRENT halo buffer; row tap dy = immediate offset dy * HWc * 64
+  unsigned raddr[2][6];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int bcol = 0; bcol < 6; ++bcol) {
+      const int x = 4 * pt + bcol;
+      raddr[g][bcol] = in_base + (prow * HWc + x) * 64 + ((((2 * g + hi) ^ (x >> 2)) & 3) << 4);
+    }
+  int rdelta = IN_BYTES;   // to the other buffer
+  auto issue_raw = [&](int dy) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int bcol = 0; bcol < 6; ++bcol) {
-        const int pl = (prow + dy) * HWc + 4 * pt + bcol;
-        const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
+        switch (dy) {
+          case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]) : "memory"); break;
+          case 1: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]), "n"(HWc * 64) : "memory"); break;
+          default: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]), "n"(2 * HWc * 64) : "memory"); break;
+        }
       }
+  };
+  auto next_buffer = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bcol = 0; bcol < 6; ++bcol) raddr[g][bcol] += rdelta;
+    rdelta = -rdelta;
   };
   auto wait_raw = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -1186,10 +1213,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
   __builtin_amdgcn_s_barrier();
 
   f32x4 a_s[2][MT];
-  issue_raw(in_base, 0);
+  issue_raw(0);
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const unsigned ibuf = in_base + (gc & 1) * IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * IN_BYTES;
       const bool more_in = gc + 1 < G;
 #pragma unroll
       for (int uc = 0; uc < UPC; ++uc) {
@@ -1211,8 +1237,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
           } else if (xh == 1) {
             // last step of the group: the next group's raw values are fetched now (its operands at the top of its first unit)
             if (next_group) {
-              if (dy < 2) issue_raw(ibuf, dy + 1);
-              else issue_raw(ibuf_next, 0);
+              if (dy < 2) {
+                issue_raw(dy + 1);
+              } else {
+                next_buffer();     // row tap 0 of the next chunk: the other halo buffer
+                issue_raw(0);
+              }
               wait_a(std::integral_constant<int, 12>(), a_s[cur]);
             } else {
               wait_a(std::integral_constant<int, 0>(), a_s[cur]);
