@@ -700,8 +700,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     wsoff += wino::WUNIT;
     if (wsoff == UT * wino::WUNIT) wsoff = 0;
   };
-  // ---- halo tile: instruction n = wave + 4 * slot covers pieces [64n, 64n + 64): pixel pl = 16n + (lane >> 2), LDS slot
-  //      lane & 3, logical piece q = slot ^ ((pl >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+  // ---- halo tile: instruction n = wave + 4 * slot covers pieces [64n, 64n + 64): pixel pl = 16n + (lane >> 2) = halo
+  //      (row ry, column rx), LDS slot lane & 3 holds logical piece (lane & 3) ^ ((rx >> 2) & 3): swizzled by the COLUMN, so a
+  //      raw read address is linear in the row tap (immediate offsets) and the slot constants do not depend on the tile
   auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
     b = tile / (p.tiles_x * p.tiles_y);
@@ -711,19 +712,20 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   unsigned ivoff[wino::NIN_W];
   int ib = 0, iy0 = 0, ix0 = 0;
   __amdgpu_buffer_rsrc_t rs0, rs1;
-  const int qdma = (l & 3) ^ ((l >> 4) & 3);
+  int slotc[wino::NIN_W];   // ry | rx << 8 | piece << 16 | valid << 24 of this lane's DMA slots (tile-independent)
+#pragma unroll
+  for (int sl = 0; sl < wino::NIN_W; ++sl) {
+    const int n = wv + 4 * sl, pl = 16 * n + (l >> 2);
+    const int ry = pl / HWc, rx = pl - ry * HWc;
+    slotc[sl] = ry | (rx << 8) | ((((l & 3) ^ ((rx >> 2) & 3))) << 16) | ((n < NIN_REAL && ry < HHr) ? (1 << 24) : 0);
+  }
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
-    const int pl0 = 16 * wv + (l >> 2);
-    int ry = pl0 / HWc, rx = pl0 - ry * HWc;
 #pragma unroll
     for (int sl = 0; sl < wino::NIN_W; ++sl) {
-      const int n = wv + 4 * sl;
-      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-      const bool ok = n < NIN_REAL && ry < HHr && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * qdma) * 4u : kOOB;
-      rx += 64;   // next slot: 64 pixels on (at most two row wraps: 64 < 2 * HWc)
-      if (rx >= HWc) { rx -= HWc; ry += 1; }
-      if (rx >= HWc) { rx -= HWc; ry += 1; }
+      const int c = slotc[sl];
+      const int iy = iy0 - 1 + (c & 0xff), ix = ix0 - 1 + ((c >> 8) & 0xff);
+      const bool ok = (c >> 24) != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * ((c >> 16) & 3)) * 4u : kOOB;
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
@@ -790,15 +792,34 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   // group's last unit (in place of that step's operand prefetch); at the top of the next unit the operand read is issued
   // first and the 32 transform instructions run under its latency.
   f32x4 V[4][2], d[2][4];
-  auto issue_raw = [&](unsigned ibuf, int dy) __attribute__((always_inline)) {
+  // raw read addresses of row tap 0 in the CURRENT halo buffer; row tap dy = immediate offset dy * HWc * 64
+  unsigned raddr[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int bcol = 0; bcol < 4; ++bcol) {
+      const int x = 2 * pt + bcol;
+      raddr[g][bcol] = in_base + (prow * HWc + x) * 64 + ((((2 * g + hi) ^ (x >> 2)) & 3) << 4);
+    }
+  int rdelta = wino::IN_BYTES;   // to the other buffer
+  auto issue_raw = [&](int dy) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int bcol = 0; bcol < 4; ++bcol) {
-        const int pl = (prow + dy) * HWc + 2 * pt + bcol;
-        const unsigned addr = ibuf + pl * 64 + ((((2 * g + hi) ^ (pl >> 2)) & 3) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(addr) : "memory");
+        switch (dy) {
+          case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]) : "memory"); break;
+          case 1: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]), "n"(HWc * 64) : "memory"); break;
+          default: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[g][bcol]) : "v"(raddr[g][bcol]), "n"(2 * HWc * 64) : "memory"); break;
+        }
       }
+  };
+  auto next_buffer = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bcol = 0; bcol < 4; ++bcol) raddr[g][bcol] += rdelta;
+    rdelta = -rdelta;
   };
   auto wait_raw = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]),
@@ -826,10 +847,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   // (from unit 2 of a chunk on: of chunk gc+1) are visible, W(gu+2) is in flight; the barrier at the end of unit gu
   // publishes W(gu+2) and frees ring slot gu % 3 for W(gu+3).
   f32x4 a_s[2][MT];
-  issue_raw(in_base, 0);
+  issue_raw(0);
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const unsigned ibuf = in_base + (gc & 1) * wino::IN_BYTES, ibuf_next = in_base + ((gc + 1) & 1) * wino::IN_BYTES;
       const bool more_in = gc + 1 < G;
 #pragma unroll
       for (int uc = 0; uc < wino::UPC; ++uc) {
@@ -852,8 +872,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
             // last step of the group: fetch the next group's raw values instead of the next unit's operands (those are read at
             // the top of the next unit, under the transform): next row tap of this chunk, or row tap 0 of the next chunk
             if (next_group) {
-              if (dy < 2) issue_raw(ibuf, dy + 1);
-              else issue_raw(ibuf_next, 0);
+              if (dy < 2) {
+                issue_raw(dy + 1);
+              } else {
+                next_buffer();     // row tap 0 of the next chunk: the other halo buffer
+                issue_raw(0);
+              }
               wait_a(std::integral_constant<int, 8>(), a_s[cur]);
             } else {
               wait_a(std::integral_constant<int, 0>(), a_s[cur]);
