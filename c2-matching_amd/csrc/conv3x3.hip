@@ -703,12 +703,24 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
   // ---- halo tile: instruction n = wave + 4 * slot covers pieces [64n, 64n + 64): pixel pl = 16n + (lane >> 2) = halo
   //      (row ry, column rx), LDS slot lane & 3 holds logical piece (lane & 3) ^ ((rx >> 2) & 3): swizzled by the COLUMN, so a
   //      raw read address is linear in the row tap (immediate offsets) and the slot constants do not depend on the tile
-  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
-    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
-    b = tile / (p.tiles_x * p.tiles_y);
-    x0 = tx * TWX;
-    y0 = ty * THY;
+  // tile coordinates are tracked incrementally (a workgroup's tiles are consecutive): integer divisions run on the vector
+  // ALU, and one per chunk plus three per tile were a measurable share of the per-tile overhead
+  struct TileCoord { int b, ty, tx; };
+  auto tc_init = [&](int tile) __attribute__((always_inline)) {
+    TileCoord t;
+    t.tx = tile % p.tiles_x;
+    t.ty = (tile / p.tiles_x) % p.tiles_y;
+    t.b = tile / (p.tiles_x * p.tiles_y);
+    return t;
   };
+  auto tc_next = [&](TileCoord& t) __attribute__((always_inline)) {
+    if (++t.tx == p.tiles_x) {
+      t.tx = 0;
+      if (++t.ty == p.tiles_y) { t.ty = 0; ++t.b; }
+    }
+  };
+  TileCoord dma_tc = tc_init(tile_first), epi_tc = dma_tc;
+  int dma_c = 0;   // chunk (inside its tile) the next issue_in() call fetches
   unsigned ivoff[wino::NIN_W];
   int ib = 0, iy0 = 0, ix0 = 0;
   __amdgpu_buffer_rsrc_t rs0, rs1;
@@ -732,11 +744,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
     return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
   };
-  auto issue_in = [&](int gc) __attribute__((always_inline)) {
-    const int it = gc / p.nchunks, c0 = (gc - it * p.nchunks) * wino::KC;
+  auto issue_in = [&](int gc) __attribute__((always_inline)) {   // called for gc = 0, 1, 2, ... in order
+    const int c0 = dma_c * wino::KC;
     const bool first = c0 < p.src[0].C;
+    if (++dma_c == p.nchunks) dma_c = 0;
     if (c0 == 0) {
-      tile_coords(tile_first + it, ib, iy0, ix0);
+      ib = dma_tc.b; iy0 = dma_tc.ty * THY; ix0 = dma_tc.tx * TWX;
+      tc_next(dma_tc);
       rs0 = src_rsrc(p.src[0], ib);
       rs1 = src_rsrc(p.src[1], ib);
       set_source(p.src[0]);
@@ -906,8 +920,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wino_kernel(Params p) {
     }
     // ---- tile epilogue: Y0 = M0 + M1 + M2 -> pixel x, Y1 = M1 - M2 - M3 -> pixel x + 1; + bias, then the mode's store
     // (pixel coordinates are derived here, not at the top of the tile: nothing of the epilogue stays live across the units)
-    int b, y0, x0;
-    tile_coords(tile_first + it, b, y0, x0);
+    int b = epi_tc.b, y0 = epi_tc.ty * THY, x0 = epi_tc.tx * TWX;
+    tc_next(epi_tc);
     asm volatile("" : "+s"(b), "+s"(y0), "+s"(x0));
     const int y = y0 + prow, x = x0 + 2 * pt;
     const bool pok = y < p.H && x < p.W;   // W is even: the pair is inside or outside as a whole
@@ -1081,12 +1095,24 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
     if (wsoff == UT * WUNIT) wsoff = 0;
   };
   // ---- halo tile (as conv3x3_wino_kernel): instruction n = wave + 4 * slot covers pieces [64n, 64n + 64)
-  auto tile_coords = [&](int tile, int& b, int& y0, int& x0) __attribute__((always_inline)) {
-    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
-    b = tile / (p.tiles_x * p.tiles_y);
-    x0 = tx * TWX;
-    y0 = ty * THY;
+  // tile coordinates are tracked incrementally (a workgroup's tiles are consecutive): integer divisions run on the vector
+  // ALU, and one per chunk plus three per tile were a measurable share of the per-tile overhead
+  struct TileCoord { int b, ty, tx; };
+  auto tc_init = [&](int tile) __attribute__((always_inline)) {
+    TileCoord t;
+    t.tx = tile % p.tiles_x;
+    t.ty = (tile / p.tiles_x) % p.tiles_y;
+    t.b = tile / (p.tiles_x * p.tiles_y);
+    return t;
   };
+  auto tc_next = [&](TileCoord& t) __attribute__((always_inline)) {
+    if (++t.tx == p.tiles_x) {
+      t.tx = 0;
+      if (++t.ty == p.tiles_y) { t.ty = 0; ++t.b; }
+    }
+  };
+  TileCoord dma_tc = tc_init(tile_first), epi_tc = dma_tc;
+  int dma_c = 0;   // chunk (inside its tile) the next issue_in() call fetches
   unsigned ivoff[NIN_W];
   int ib = 0, iy0 = 0, ix0 = 0;
   __amdgpu_buffer_rsrc_t rs0, rs1;
@@ -1112,11 +1138,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
     const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
     return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
   };
-  auto issue_in = [&](int gc) __attribute__((always_inline)) {
-    const int it = gc / p.nchunks, c0 = (gc - it * p.nchunks) * KC;
+  auto issue_in = [&](int gc) __attribute__((always_inline)) {   // called for gc = 0, 1, 2, ... in order
+    const int c0 = dma_c * KC;
     const bool first = c0 < p.src[0].C;
+    if (++dma_c == p.nchunks) dma_c = 0;
     if (c0 == 0) {
-      tile_coords(tile_first + it, ib, iy0, ix0);
+      ib = dma_tc.b; iy0 = dma_tc.ty * THY; ix0 = dma_tc.tx * TWX;
+      tc_next(dma_tc);
       rs0 = src_rsrc(p.src[0], ib);
       rs1 = src_rsrc(p.src[1], ib);
       set_source(p.src[0]);
@@ -1294,8 +1322,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino4_kernel(Params p) {
       }
     }
     // ---- tile epilogue: Y = A^T M (bias already inside M1), activation, residuals, four channels-last pixels per lane
-    int b, y0, x0;
-    tile_coords(tile_first + it, b, y0, x0);
+    int b = epi_tc.b, y0 = epi_tc.ty * THY, x0 = epi_tc.tx * TWX;
+    tc_next(epi_tc);
     asm volatile("" : "+s"(b), "+s"(y0), "+s"(x0));
     const int y = y0 + prow, x = x0 + 4 * pt;
     const bool pok = y < p.H && x < p.W;   // W % 64 == 0: the quad is inside or outside as a whole
