@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_kernel(Params p) {
 // as the direct kernel: buffer-addressed LDS-DMA with hardware zero fill, 8 KiB weight units in a ring of 3 (two units
 // ahead), b128 operand reads with hand-placed waits, persistent tiles.
 //   workgroup = 4 waves = 64 x 4 pixels (wave = row, lane (hi, j) = pixel pair j) or 32 x 8 (wave = two rows of 16 pairs)
-//   chunk = 16 input channels (64-byte pixel rows in LDS, pieces swizzled by (pixel >> 2) & 3; the stride-2 pair access
+//   chunk = 16 input channels (64-byte pixel rows in LDS, pieces swizzled by the halo column, (x >> 2) & 3; the stride-2 pair access
 //   leaves a 2-way conflict on the 8 raw reads per 64 MFMAs), unit = (chunk, dy, two xi) = 32 MFMAs per wave
 // fp32 throughout; results differ from the direct kernel by the rounding of the transforms (tested at 2e-5 * scale).
 // =====================================================================================================================
