@@ -283,8 +283,8 @@ def _wino_ok(srcs, weight, out_mode, W):
 
 
 def _wino4_ok(srcs, weight, out_mode, W):
-    """Winograd F(4,3)-along-x kernel: as F(2,3) but whole 64-pixel tiles along x."""
-    return _WINO4 and W % 64 == 0 and _wino_ok(srcs, weight, out_mode, W)
+    """Winograd F(4,3)-along-x kernel: as F(2,3) but plain channels-last output and whole 64-pixel tiles along x."""
+    return _WINO4 and W % 64 == 0 and out_mode == "nhwc" and _wino_ok(srcs, weight, out_mode, W)
 
 
 def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,

@@ -263,3 +263,40 @@ def test_weight_cache_entries_belong_to_one_tensor_object():
     del w
     gc.collect()
     assert len(c._d) == 0
+
+
+def test_pool_fusion_predicate_and_grouped_twin_validation():
+    """Host-side decisions of ops.vgg_stack_forward / conv3x3 that do not need a GPU: which MaxPool2d a convolution epilogue
+    may absorb, and the shape contract of the group-major twin buffer."""
+    import pytest
+    import torch
+    from c2m_amd import ops, _lib
+    assert ops._pool_is_2x2(torch.nn.MaxPool2d(2, 2))
+    assert ops._pool_is_2x2(torch.nn.MaxPool2d(kernel_size=(2, 2), stride=(2, 2), padding=0))
+    assert not ops._pool_is_2x2(torch.nn.MaxPool2d(3, 2, 1))
+    assert not ops._pool_is_2x2(torch.nn.MaxPool2d(2, 1))
+    assert not ops._pool_is_2x2(torch.nn.MaxPool2d(2, 2, ceil_mode=True))
+    dev = torch.device("cpu")
+    assert ops._grouped8_args(None, 1, 64, 4, 4, dev) == (None, 0, 0, 0)
+    good = torch.zeros(2, 8, 7, 9, 8)
+    ptr, row, plane, img = ops._grouped8_args(good, 2, 64, 4, 6, dev)
+    assert (row, plane, img) == (9 * 8, 7 * 9 * 8, 8 * 7 * 9 * 8) and ptr == good.data_ptr() + (9 + 1) * 8 * 4
+    for bad in (torch.zeros(2, 8, 7, 9, 4), torch.zeros(2, 8, 7, 9, 8, dtype=torch.float64), torch.zeros(2, 7, 8, 9, 8)):
+        with pytest.raises(_lib.C2MError):
+            ops._grouped8_args(bad, 2, 64, 4, 6, dev)
+
+
+def test_conv_algo_selection_is_shape_driven():
+    """ops._wino_ok / _wino4_ok: F(2,3) needs 64-channel output tiles, 16-channel sources and whole 32-pixel tiles; F(4,3)
+    additionally whole 64-pixel tiles and a plain channels-last output (it is what conv3x3(fast=True) may pick)."""
+    import torch
+    from c2m_amd import ops
+    w64 = torch.zeros(64, 64, 3, 3)
+    src = lambda c, w: [torch.zeros(1, c, 8, w)]   # noqa: E731
+    assert ops._wino_ok(src(64, 160), w64, "nhwc", 160) and not ops._wino4_ok(src(64, 160), w64, "nhwc", 160)
+    assert ops._wino4_ok(src(64, 640), w64, "nhwc", 640)
+    assert not ops._wino4_ok(src(64, 640), w64, "nhwc_pool2", 640) and ops._wino_ok(src(64, 640), w64, "nhwc_pool2", 640)
+    assert not ops._wino_ok(src(64, 40), w64, "nhwc", 40)                         # ragged width
+    assert not ops._wino_ok(src(64, 64), torch.zeros(32, 64, 3, 3), "nhwc", 64)   # 32 output channels
+    assert not ops._wino_ok(src(64, 64), w64, "nchw", 64)
+    assert not ops._wino_ok([torch.zeros(1, 24, 8, 64), torch.zeros(1, 40, 8, 64)], w64, "nhwc", 64)   # 24-channel source
