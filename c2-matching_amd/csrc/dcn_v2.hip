@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) nchw_to_grouped_kernel(const float* __res
 //     [K/8][CoPad][8] (weight_relayout_bf16_kernel), the blended column values are rounded to bf16 (RNE) in registers.
 //     Gathers, sampling state and blend stay fp32.  For callers that ask for reduced precision (bf16 autocast).
 template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
-__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : 2) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
+__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16 && MT <= 2) ? 4 : 2)) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
