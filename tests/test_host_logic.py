@@ -300,3 +300,31 @@ def test_conv_algo_selection_is_shape_driven():
     assert not ops._wino_ok(src(64, 64), torch.zeros(32, 64, 3, 3), "nhwc", 64)   # 32 output channels
     assert not ops._wino_ok(src(64, 64), w64, "nchw", 64)
     assert not ops._wino_ok([torch.zeros(1, 24, 8, 64), torch.zeros(1, 40, 8, 64)], w64, "nhwc", 64)   # 24-channel source
+
+
+def test_cpu_chain_mismatch_margins_scores_both_picks():
+    """oracle/cpu_chain.mismatch_margins (bench.py's near-tie diagnostic): for every query where two index maps disagree it
+    reports score(pick_a) - score(pick_b) in float64 with ref_map_util.py:52-76's normalisation -- zero for an exact
+    duplicate patch, and equal to the oracle's score difference otherwise."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import cpu_chain
+    g = torch.Generator().manual_seed(3)
+    f1, f2 = torch.randn(8, 9, 9, generator=g), torch.randn(8, 9, 9, generator=g)
+    f2[:, 4:7, 4:7] = f2[:, 0:3, 0:3]            # ref patch (4, 4) duplicates ref patch (0, 0)
+    wq = 7
+    a = np.zeros((7, 7), dtype=np.int64)
+    b = a.copy()
+    b[2, 3] = 4 * wq + 4                          # the duplicate: an exact tie
+    b[5, 1] = 3 * wq + 2                          # some other patch
+    out = cpu_chain.mismatch_margins(f1, f2, a, b)
+    assert [o[0] for o in out] == [(2, 3), (5, 1)] and out[0][1:3] == (0, 4 * wq + 4)
+    assert abs(out[0][3]) < 1e-12
+    n1 = torch.nn.functional.normalize(f1.reshape(8, -1), dim=0).view(8, 9, 9).double().numpy()
+    n2 = torch.nn.functional.normalize(f2.reshape(8, -1), dim=0).view(8, 9, 9).double().numpy()
+    sc = lambda ry, rx: float((n1[:, 5:8, 1:4] * n2[:, ry:ry + 3, rx:rx + 3]).sum() /   # noqa: E731
+                              (np.sqrt((n2[:, ry:ry + 3, rx:rx + 3] ** 2).sum()) + 1e-5))
+    assert abs(out[1][3] - (sc(0, 0) - sc(3, 2))) < 1e-12
