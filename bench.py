@@ -223,7 +223,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("C2M_BENCH_FORCE_DIST") == "1":   # (the env var: exercise the RCCL path on a 1-GPU box)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for the barrier + max only
 
