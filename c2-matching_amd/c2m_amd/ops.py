@@ -61,28 +61,57 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
                                                  sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
                                                  idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes),
                    "c2m_feature_match_index_f32")
-        global _last_corr
-        _last_corr = (ws, (B, Hq, Wq, Hr, Wr))
-        if return_skip:
-            return idx, val, last_corr_skip_table()
+        mfma = (not force_generic) and p == 3 and si == 1 and sr == 1 and C in (64, 128, 256)   # the C-ABI's own dispatch rule
+        if return_skip or _corr_diag.enabled:
+            # diagnostics only (bench.py's swept-row count, the dedup tests): the duplicate-row table exists only when the
+            # MFMA kernel ran; nothing is kept otherwise, so the workspace dies with the call and no module state is
+            # touched on the product path (DataParallel replicas run this function concurrently)
+            table = _skip_table(ws, (B, Hq, Wq, Hr, Wr)) if mfma else None
+            if _corr_diag.enabled:
+                _corr_diag.table = table
+            if return_skip:
+                if table is None:
+                    raise _lib.C2MError("return_skip: the duplicate-row table exists only on the MFMA kernel's path "
+                                        "(patch 3, strides 1, C in 64/128/256, force_generic=False)")
+                return idx, val, table
     return idx, val
 
 
-_last_corr = None
+class _CorrDiag:
+    """Opt-in diagnostics of the correlation launch: `with ops.record_corr_skip_table(): ...` keeps the duplicate-row table
+    of the most recent MFMA launch inside the block (a small int32 tensor, not the workspace)."""
+    enabled = False
+    table = None
 
 
-def last_corr_skip_table():
-    """Duplicate-row table of the most recent feature_match_index_batched call: int32 [B, x_tiles, 2] = (from, to), ref
-    rows [from, to) of that (sample, x-tile) were not swept (c2m_feature_match_skip_table).  Diagnostics / bench only."""
+_corr_diag = _CorrDiag()
+
+
+class record_corr_skip_table:
+    def __enter__(self):
+        _corr_diag.enabled, _corr_diag.table = True, None
+        return self
+
+    def __exit__(self, *exc):
+        _corr_diag.enabled = False
+        return False
+
+
+def _skip_table(ws, shp):
     import ctypes
-    if _last_corr is None:
-        raise _lib.C2MError("no correlation has run yet")
-    ws, shp = _last_corr
     off, nxt = ctypes.c_size_t(0), ctypes.c_int(0)
     _lib.check(_lib.lib().c2m_feature_match_skip_table(*shp, ctypes.byref(off), ctypes.byref(nxt)),
                "c2m_feature_match_skip_table")
     B = shp[0]
     return ws[off.value:off.value + 8 * B * nxt.value].view(torch.int32).view(B, nxt.value, 2).clone()
+
+
+def last_corr_skip_table():
+    """Duplicate-row table recorded under `record_corr_skip_table()`: int32 [B, x_tiles, 2] = (from, to), ref rows
+    [from, to) of that (sample, x-tile) were not swept (c2m_feature_match_skip_table).  Diagnostics / bench only."""
+    if _corr_diag.table is None:
+        raise _lib.C2MError("no MFMA correlation launch was recorded (use `with ops.record_corr_skip_table():`)")
+    return _corr_diag.table
 
 
 def build_pre_offsets(max_idx, h, w, scales=(1, 2, 4)):
@@ -186,23 +215,57 @@ def dcn_fuse_offsets(conv_out, pre_offset, deformable_groups, kernel_taps, abs_s
 # 3x3 convolution, channels-last, fused epilogue (csrc/conv3x3.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-_conv_flops = [0.0, 0.0]   # algorithmic (direct-convolution) flops, flops the MFMAs actually execute
+class _ConvFlops:
+    """Opt-in FLOP accounting of the conv3x3 launches (bench.py's roofline line): off on the product path -- nothing is
+    counted and no module state is written unless a caller enabled it with count_conv_flops(True)."""
+    enabled = False
+    algorithmic = 0.0    # direct-convolution flops 2*Cout*9*Cin*H*W*B
+    executed = 0.0       # flops the matrix instructions actually perform (F(2,3): 2/3, F(4,3): 1/2 of the direct count)
+    by_algo = None       # {kernel family: [launches, algorithmic, executed]}
+
+    @classmethod
+    def add(cls, family, algo, execd):
+        if cls.enabled:
+            cls.algorithmic += algo
+            cls.executed += execd
+            e = cls.by_algo.setdefault(family, [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += algo
+            e[2] += execd
+
+
+def count_conv_flops(on=True):
+    """Enable / disable the accounting and reset the counters."""
+    _ConvFlops.enabled = bool(on)
+    _ConvFlops.algorithmic = _ConvFlops.executed = 0.0
+    _ConvFlops.by_algo = {}
 
 
 def conv_flops_of_last_steps(reset=True, executed=False):
-    """2*Cout*9*Cin*H*W*B summed over the conv3x3 calls since the last reset (bench.py's roofline line); executed=True: the
-    flops the matrix instructions really perform (Winograd F(2,3) launches execute 2/3 of the direct count)."""
-    v = _conv_flops[1 if executed else 0]
+    """2*Cout*9*Cin*H*W*B summed over the conv3x3 calls since the last reset (needs count_conv_flops(True)); executed=True:
+    the flops the matrix instructions really perform (Winograd F(2,3) launches execute 2/3 of the direct count)."""
+    v = _ConvFlops.executed if executed else _ConvFlops.algorithmic
     if reset:
-        _conv_flops[0] = _conv_flops[1] = 0.0
+        _ConvFlops.algorithmic = _ConvFlops.executed = 0.0
+        _ConvFlops.by_algo = {}
     return v
+
+
+def conv_flops_by_family():
+    return {k: list(v) for k, v in (_ConvFlops.by_algo or {}).items()}
 
 
 class _WeightCache:
     """Re-laid-out conv weights, keyed by the parameter tensor and its version counter: inference re-uses them across
     calls; an optimiser step (in-place update -> new _version) or load_state_dict invalidates them.  An entry belongs to
     one tensor OBJECT (weak reference): a new parameter that happens to reuse a dead one's id, address and version never
-    hits its entry, and entries die with their tensor."""
+    hits its entry, and entries die with their tensor.
+
+    Writes through ``param.data`` (the reference's own init_offset / default_init_weights idiom, EMA updates, manual
+    copies) do NOT bump ``_version``: ``refresh()`` re-runs the re-layout of the live entries from the tensors' current
+    contents (a few microseconds of GPU time per entry, no host sync) and the fused inference entry points call it once
+    per forward for the parameters of their module (refresh_weight_caches), so a cached image is never older than the
+    forward that uses it; ``clear()`` drops everything (clear_weight_caches)."""
 
     def __init__(self):
         self._d = {}
@@ -213,7 +276,7 @@ class _WeightCache:
             return hit[1]
         return None
 
-    def _store(self, slot, key, weight, value):
+    def _store(self, slot, key, weight, value, redo=None):
         import weakref
         d = self._d
 
@@ -221,14 +284,26 @@ class _WeightCache:
             cur = d.get(slot)
             if cur is not None and cur[2] is ref:
                 del d[slot]
-        self._d[slot] = (key, value, weakref.ref(weight, _drop))
+        self._d[slot] = (key, value, weakref.ref(weight, _drop), redo)
 
-    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3) layout
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
-        slot = (id(weight), rows, wino)
-        hit = self._lookup(slot, key, weight)
-        if hit is not None:
-            return hit
+    def clear(self):
+        self._d.clear()
+
+    def refresh(self, param_ids=None):
+        """Re-run the re-layout kernels of the live entries (of the tensors whose id() is in param_ids, or all)."""
+        n = 0
+        for slot, (key, value, ref, redo) in list(self._d.items()):
+            w = ref()
+            if w is None or redo is None or (param_ids is not None and id(w) not in param_ids):
+                continue
+            if key[0] != w.data_ptr() or key[1] != w._version:
+                continue        # stale by key: the next get() rebuilds it anyway
+            redo(w, value)
+            n += 1
+        return n
+
+    @staticmethod
+    def _relayout(weight, rows, pad_cin_to, wino, wr=None):
         w = weight.detach()
         if rows is not None:
             w = w[rows[0]:rows[1]]
@@ -245,11 +320,22 @@ class _WeightCache:
         if nbytes == 0:
             raise _lib.C2MError(f"conv3x3: unsupported channel counts Cin={Ci}, Cout={Co}" + (" for the Winograd kernel" if wino else
                                 " (input channels must be a multiple of 32)"))
-        wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        if wr is None:
+            wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             fn = (L.c2m_conv3x3_relayout_f32, L.c2m_conv3x3_relayout_wino_f32, L.c2m_conv3x3_relayout_wino4_f32)[wino]
             _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
-        self._store(slot, key, weight, wr)
+        return wr
+
+    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3) layout
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
+        slot = (id(weight), rows, wino)
+        hit = self._lookup(slot, key, weight)
+        if hit is not None:
+            return hit
+        wr = self._relayout(weight, rows, pad_cin_to, wino)
+        self._store(slot, key, weight, wr,
+                    redo=lambda w, buf, rows=rows, pad=pad_cin_to, wino=wino: self._relayout(w, rows, pad, wino, buf))
         return wr
 
 
@@ -360,8 +446,9 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     d.out = out.data_ptr()
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
-    _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
-    _conv_flops[1] += 2.0 * Cout * (9, 6, 4.5)[wino] * Cin * H * W * B
+    if _ConvFlops.enabled:
+        _ConvFlops.add(("direct", "winograd_f23", "winograd_f43")[wino], 2.0 * Cout * 9 * Cin * H * W * B,
+                       2.0 * Cout * (9, 6, 4.5)[wino] * Cin * H * W * B)
     return out
 
 
@@ -404,8 +491,8 @@ def conv3x3_rgb64(image, weight, bias=None, act=ACT_NONE, slope=0.1, mean=None, 
             mean.data_ptr() if mean is not None else None, std.data_ptr() if std is not None else None, int(act),
             float(slope), out.data_ptr(), o.pix_pitch, o.row_pitch, o.img_pitch, o2, o2_row, o2_plane, o2_img),
             "c2m_conv3x3_rgb64_f32")
-    _conv_flops[0] += 2.0 * 64 * 27 * H * W * B
-    _conv_flops[1] += 2.0 * 64 * 28 * H * W * B
+    if _ConvFlops.enabled:
+        _ConvFlops.add("rgb_first_layer", 2.0 * 64 * 27 * H * W * B, 2.0 * 64 * 28 * H * W * B)
     return out
 
 
@@ -466,9 +553,11 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
             d.abs_sum = abs_sum.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
-    _conv_flops[0] += 2.0 * Cout * 9 * Cin * H * W * B
-    _conv_flops[1] += sum(2.0 * (c1 - c0) * (6 if (_WINO and (c1 - c0) % 64 == 0 and W % 32 == 0) else 9) * Cin * H * W * B
-                          for (c0, c1) in slices)
+    if _ConvFlops.enabled:
+        for (c0, c1) in slices:
+            w_ = _WINO and (c1 - c0) % 64 == 0 and W % 32 == 0
+            _ConvFlops.add("dcn_head_f23" if w_ else "dcn_head_direct", 2.0 * (c1 - c0) * 9 * Cin * H * W * B,
+                           2.0 * (c1 - c0) * (6 if w_ else 9) * Cin * H * W * B)
     return offset, mask
 
 
@@ -502,25 +591,50 @@ class BorderedNHWC:
 
 
 class _DcnWeightCache(_WeightCache):
-    def get(self, weight, dg):
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), dg, weight.device.index)
-        hit = self._lookup(id(weight), key, weight)
-        if hit is not None:
-            return hit
+    @staticmethod
+    def _relayout_dcn(weight, dg, wt=None):
         w = _dev_f32(weight.detach(), "weight")
         Co, C, kh, kw = w.shape
         L = _lib.lib()
         nbytes = L.c2m_dcn_v2_relayout_bytes(C, Co, kh, kw, dg)
         if nbytes == 0:
             raise _lib.C2MError("dcn_v2_forward_nhwc: geometry is not on the channels-last path")
-        wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        if wt is None:
+            wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(L.c2m_dcn_v2_relayout_f32(_stream(), w.data_ptr(), C, Co, kh, kw, dg, wt.data_ptr()), "c2m_dcn_v2_relayout_f32")
-        self._store(id(weight), key, weight, wt)
+        return wt
+
+    def get(self, weight, dg):
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), dg, weight.device.index)
+        hit = self._lookup(id(weight), key, weight)
+        if hit is not None:
+            return hit
+        wt = self._relayout_dcn(weight, dg)
+        self._store(id(weight), key, weight, wt, redo=lambda w, buf, dg=dg: self._relayout_dcn(w, dg, buf))
         return wt
 
 
 _dcn_wcache = _DcnWeightCache()
+
+
+def refresh_weight_caches(module_or_params=None):
+    """Rebuild the cached weight images (conv3x3 re-layouts, DCNv2 re-layouts) of the given module's / iterable's
+    parameters -- or of every live entry -- from the tensors' CURRENT contents.  The fused inference entry points call
+    this once per forward: in-place writes through ``param.data`` do not bump the version counter the caches are keyed
+    on, so without it such an update would keep computing with the old weights.  Returns the number of
+    images rebuilt.  No host synchronisation."""
+    ids = None
+    if module_or_params is not None:
+        params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
+        ids = {id(p) for p in params}
+    return _wcache.refresh(ids) + _dcn_wcache.refresh(ids)
+
+
+def clear_weight_caches():
+    """Drop every cached weight image (they are rebuilt on the next use)."""
+    _wcache.clear()
+    _dcn_wcache.clear()
 
 
 def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_groups, act=ACT_NONE, slope=0.1,
@@ -602,6 +716,8 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
     names = list(layers.keys())
     B, C, H, W = x.shape
     dev = x.device
+    # cached weight images follow in-place writes through .data (which the version counter does not see)
+    _wcache.refresh({id(p_) for layer_ in layers.values() for p_ in layer_.parameters()})
     first = layers[names[0]]
     rgb64 = C == 3 and isinstance(first, torch.nn.Conv2d) and tuple(first.weight.shape) == (64, 3, 3, 3)
     if rgb64:

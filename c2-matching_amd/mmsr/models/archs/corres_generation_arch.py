@@ -22,17 +22,38 @@ class PreOffsets(dict):
     """The ``pre_offset`` dict of the reference (keys relu3_1 / relu2_1 / relu1_1 -> [B, 9, s*h, s*w, 2] float32, last dim
     (x, y), s = 1 / 2 / 4; corres_generation_arch.py:69-109), built LAZILY from the arg-max index map.
 
-    Any consumer that indexes it gets exactly the reference's tensors (one kernel launch per scale on first access).  The
-    fused decoder path of ``RestorationNet`` never does: it hands ``flow`` (index_to_flow of the whole batch, [B,h-2,w-2,2])
-    to the DCN offset/mask head kernel, which synthesises the shifted / up-scaled / repeated offsets on the fly -- the
-    three tensors (59 + 236 + 944 MB at batch 16, LR 160) are then never materialised."""
+    What the dict STORES is the index map (key ``max_idx``, int64 [B, h-2, w-2]) plus whichever of the three tensors have
+    been asked for so far.  ``pre_offset[key]``, ``key in pre_offset`` and ``.get(key)`` behave like the reference's dict
+    (the tensor is produced by one kernel launch on first access and then kept); iteration / ``items()`` show the stored
+    entries only.  That is what makes the object safe to hand to a wrapped ``net_g``: DistributedDataParallel and
+    DataParallel rebuild dict inputs as ``type(obj)(pairs)`` after moving / slicing every VALUE along dim 0
+    (torch.distributed.utils._recursive_to, nn.parallel.scatter_gather.scatter) -- here the pairs are ``max_idx`` (batch
+    along dim 0, so a DataParallel replica receives its slice) and nothing is materialised on the way; ``h, w`` are
+    recovered from the map (3x3 patches at stride 1: h = hq + 2).
+
+    The fused decoder path of ``RestorationNet`` never indexes the scales: it hands ``flow`` (index_to_flow of the whole
+    batch, [B, h-2, w-2, 2]) to the DCN offset/mask head kernel, which synthesises the shifted / up-scaled / repeated
+    offsets on the fly -- the three tensors (59 + 236 + 944 MB at batch 16, LR 160) are then never materialised."""
 
     _SCALE = {'relu3_1': 1, 'relu2_1': 2, 'relu1_1': 4}
 
-    def __init__(self, max_idx, h, w):
+    def __init__(self, max_idx, h=None, w=None):
         super().__init__()
-        self.max_idx, self.h, self.w = max_idx, int(h), int(w)
+        if isinstance(max_idx, torch.Tensor):
+            dict.__setitem__(self, 'max_idx', max_idx)
+        else:   # a mapping / an iterable of (key, value) pairs: the rebuild after a DDP / DataParallel input scatter
+            for k, v in dict(max_idx).items():
+                dict.__setitem__(self, k, v)
+            if not dict.__contains__(self, 'max_idx'):
+                raise TypeError("PreOffsets needs the arg-max index map (a tensor, or a mapping with key 'max_idx')")
+        mi = dict.__getitem__(self, 'max_idx')
+        self.h = int(h) if h is not None else mi.shape[-2] + 2
+        self.w = int(w) if w is not None else mi.shape[-1] + 2
         self._flow = None
+
+    @property
+    def max_idx(self):
+        return dict.__getitem__(self, 'max_idx')
 
     @property
     def flow(self):
@@ -44,29 +65,17 @@ class PreOffsets(dict):
         if key not in self._SCALE:
             raise KeyError(key)
         (t,) = _ops.build_pre_offsets(self.max_idx, self.h, self.w, scales=(self._SCALE[key],))
-        self[key] = t
+        dict.__setitem__(self, key, t)
         return t
 
     def __contains__(self, key):
-        return key in self._SCALE
-
-    def __iter__(self):
-        return iter(self._SCALE)
-
-    def __len__(self):
-        return len(self._SCALE)
-
-    def keys(self):
-        return self._SCALE.keys()
-
-    def values(self):
-        return [self[k] for k in self._SCALE]
-
-    def items(self):
-        return [(k, self[k]) for k in self._SCALE]
+        return key in self._SCALE or dict.__contains__(self, key)
 
     def get(self, key, default=None):
-        return self[key] if key in self._SCALE else default
+        return self[key] if key in self else default
+
+    def __reduce__(self):   # pickling / copy.deepcopy: the stored entries travel, the cached flow map does not
+        return (type(self), (dict(self.items()), self.h, self.w))
 
 
 class CorrespondenceGenerationArch(nn.Module):

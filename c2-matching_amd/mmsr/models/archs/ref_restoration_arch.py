@@ -49,6 +49,10 @@ class ContentExtractor(nn.Module):
         return _fused_body(self.body, f)
 
 
+def _has_hooks(module):
+    return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
+
+
 def _fusable_body(body):
     return all(isinstance(b, arch_util.ResidualBlockNoBN) and b.res_scale == 1 for b in body)
 
@@ -131,6 +135,12 @@ class DynamicAggregationRestoration(nn.Module):
         return all(_fusable_body(getattr(self, f'body_{n}')) and getattr(self, f'{n}_dyn_agg').deformable_groups == 8
                    for n, _, _ in self._STAGES)
 
+    def has_inner_hooks(self):
+        """Forward (pre-)hooks registered on anything but the three DynAgg modules (whose boundary the fused path keeps):
+        the fused path calls ops.conv3x3 on the sub-modules' parameters directly, so such hooks would silently not fire."""
+        dyn = {id(getattr(self, f'{n}_dyn_agg')) for n, _, _ in self._STAGES}
+        return any(id(m) not in dyn and m is not self and (m._forward_hooks or m._forward_pre_hooks) for m in self.modules())
+
 
 class RestorationNet(nn.Module):
 
@@ -147,20 +157,36 @@ class RestorationNet(nn.Module):
             head.weight.data.zero_()
             head.bias.data.zero_()
 
+    #: set to False on an instance (or the class) to keep every forward on the module-by-module path (debugging, feature
+    #: capture); forward hooks registered on inner modules switch the fused path off by themselves
+    allow_fused = True
+
     def _use_fused(self, x, pre_offset, img_ref_feat):
         from mmsr.models.archs.corres_generation_arch import PreOffsets
+        if not self.allow_fused:
+            return False
         if torch.is_grad_enabled() or not isinstance(pre_offset, PreOffsets) or not x.is_cuda or x.dtype != torch.float32:
             return False
         if torch.is_autocast_enabled('cuda'):   # reduced-precision inference (BASELINE configs[4]) keeps the bf16 convs
             return False
         ok_feats = all(img_ref_feat[k].dtype == torch.float32 and img_ref_feat[k].shape[1] == c
                        for _, k, c in DynamicAggregationRestoration._STAGES)
-        return ok_feats and _fusable_body(self.content_extractor.body) and self.dyn_agg_restore.fusable()
+        if not (ok_feats and _fusable_body(self.content_extractor.body) and self.dyn_agg_restore.fusable()):
+            return False
+        if self.dyn_agg_restore.has_inner_hooks() or _has_hooks(self.content_extractor):
+            return False   # forward hooks on inner modules only fire on the module-by-module path
+        # size limits of the fused kernels (32-bit byte offsets inside one sample: the planar offset/mask planes of the
+        # largest DCN head, 27*dg channels at 4h x 4w, are the first to overflow; C2M_ERR_UNSUPPORTED otherwise):
+        # larger outputs run module by module instead of raising in the middle of the forward
+        h, w = x.shape[2:]
+        dg = self.dyn_agg_restore.large_dyn_agg.deformable_groups
+        return 27 * dg * (4 * h) * (4 * w) * 4 < 2 ** 31 - 1
 
     def forward(self, x, pre_offset, img_ref_feat):
         """x: LR image [B,3,h,w]; pre_offset / img_ref_feat: dicts keyed relu3_1 / relu2_1 / relu1_1."""
         base = F.interpolate(x, None, 4, 'bilinear', False)
         if self._use_fused(x, pre_offset, img_ref_feat):
+            _ops.refresh_weight_caches(self)   # cached weight images follow writes through .data (no version bump)
             content_feat = self.content_extractor.forward_fused(x)
             return self.dyn_agg_restore.forward_fused(content_feat, pre_offset.flow, img_ref_feat) + base
         content_feat = self.content_extractor(x)

@@ -85,3 +85,5 @@ class BaseModel:
         raw = torch.load(load_path, map_location='cpu')
         state = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in raw.items())
         net.load_state_dict(state, strict=strict)
+        from c2m_amd import ops as _ops
+        _ops.clear_weight_caches()   # (load_state_dict bumps the version counters; this also frees the old images)

@@ -328,3 +328,59 @@ def test_cpu_chain_mismatch_margins_scores_both_picks():
     sc = lambda ry, rx: float((n1[:, 5:8, 1:4] * n2[:, ry:ry + 3, rx:rx + 3]).sum() /   # noqa: E731
                               (np.sqrt((n2[:, ry:ry + 3, rx:rx + 3] ** 2).sum()) + 1e-5))
     assert abs(out[1][3] - (sc(0, 0) - sc(3, 2))) < 1e-12
+
+
+def test_pre_offsets_survive_the_ddp_and_dataparallel_input_scatter():
+    """RefRestorationModel hands `pre_offset` to a wrapped net_g as a positional input; DistributedDataParallel and
+    DataParallel rebuild dict inputs as type(obj)(pairs) after moving / slicing every value.  The
+    rebuilt object must still be a PreOffsets carrying the index map, and nothing may be materialised on the way (no
+    kernel can run here: there is no GPU, so a materialisation attempt would raise)."""
+    import copy
+    import pickle
+    from torch.distributed.utils import _recursive_to
+    from torch.nn.parallel.scatter_gather import scatter_kwargs  # noqa: F401  (import check only)
+    from mmsr.models.archs.corres_generation_arch import PreOffsets
+    idx = torch.arange(2 * 6 * 7, dtype=torch.int64).view(2, 6, 7)
+    pre = PreOffsets(idx, 8, 9)
+    x = torch.zeros(2, 3, 8, 9)
+    (moved,) = _recursive_to((x, pre, {"relu1_1": x}), torch.device("cpu"), False)
+    assert type(moved[1]) is PreOffsets and moved[1].max_idx is idx and (moved[1].h, moved[1].w) == (8, 9)
+    assert list(moved[1].keys()) == ["max_idx"]                      # still lazy
+    assert "relu3_1" in pre and "relu1_1" in pre and "nope" not in pre
+    # DataParallel's scatter_map on a dict: type(obj)(pairs) per replica with the values sliced along dim 0
+    halves = [PreOffsets([("max_idx", part)]) for part in idx.chunk(2, 0)]
+    assert [tuple(h_.max_idx.shape) for h_ in halves] == [(1, 6, 7)] * 2 and (halves[0].h, halves[0].w) == (8, 9)
+    for clone in (copy.deepcopy(pre), pickle.loads(pickle.dumps(pre))):
+        assert type(clone) is PreOffsets and torch.equal(clone.max_idx, idx) and (clone.h, clone.w) == (8, 9)
+    with pytest.raises(TypeError):
+        PreOffsets({"relu3_1": x})
+    with pytest.raises(KeyError):
+        pre["relu9_9"]
+
+
+def test_weight_cache_refresh_follows_writes_through_data():
+    """`p.data.copy_()` leaves `p._version` alone, so the (data_ptr, _version) key of the weight caches
+    cannot see it.  refresh() re-runs the stored re-layout of the live entries -- of the given parameters only -- from the
+    tensors' current contents; entries whose key is stale anyway are left to get()."""
+    import torch
+    from c2m_amd import ops
+    c = ops._WeightCache()
+    w1, w2 = torch.nn.Parameter(torch.zeros(2, 2, 3, 3)), torch.nn.Parameter(torch.ones(2, 2, 3, 3))
+    calls = []
+
+    def redo(w, buf):
+        buf.copy_(w.detach().flatten()[:4] * 2)
+        calls.append(id(w))
+    for slot, w in (("a", w1), ("b", w2)):
+        c._store((slot,), (w.data_ptr(), w._version), w, torch.zeros(4), redo=redo)
+    v0 = w1._version
+    w1.data.fill_(3.0)
+    assert w1._version == v0                                         # the blind spot
+    assert c.refresh({id(w1)}) == 1 and calls == [id(w1)]
+    assert torch.equal(c._lookup(("a",), (w1.data_ptr(), w1._version), w1), torch.full((4,), 6.0))
+    assert c.refresh() == 2
+    with torch.no_grad():
+        w2.add_(1.0)                                                 # a real in-place update: key is stale, get() handles it
+    assert c.refresh({id(w2)}) == 0
+    c.clear()
+    assert c.refresh() == 0
