@@ -240,13 +240,14 @@ def main():
     def timed(step_fn):
         for _ in range(args.warmup):
             step_fn()
-        ops.conv_flops_of_last_steps()   # reset the conv FLOP counters: only the timed steps count
+        ops.count_conv_flops(True)   # (re)start the opt-in conv FLOP accounting: only the timed steps count
         c2m_amd.profile_enable(True)
         c2m_amd.profile_collect()
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step_fn()
+        with ops.record_corr_skip_table():
+            for _ in range(args.steps):
+                out = step_fn()
         sync()
         dt = time.perf_counter() - t0
         timed.conv_flops_exec = ops.conv_flops_of_last_steps(reset=False, executed=True)

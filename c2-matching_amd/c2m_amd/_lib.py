@@ -76,6 +76,9 @@ def _declare(L):
     L.c2m_conv3x3_relayout_wino4_bytes.restype = _sz
     L.c2m_conv3x3_relayout_wino4_bytes.argtypes = [_i, _i]
     L.c2m_conv3x3_relayout_wino4_f32.argtypes = [_vp, _vp, _i, _i, _vp]
+    L.c2m_conv3x3_relayout_split_bytes.restype = _sz
+    L.c2m_conv3x3_relayout_split_bytes.argtypes = [_i, _i, _i]
+    L.c2m_conv3x3_relayout_split_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     L.c2m_conv3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(Conv3x3Desc)]
     L.c2m_index_to_flow_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
 

@@ -316,18 +316,26 @@ class _WeightCache:
         w = w.contiguous()
         L = _lib.lib()
         wino = int(wino)
-        nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
+        if wino in (3, 4):   # split-bf16 images (3 exact pieces / 1 rounded piece per weight)
+            pieces = 3 if wino == 3 else 1
+            nbytes = L.c2m_conv3x3_relayout_split_bytes(Ci, Co, pieces)
+        else:
+            nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
         if nbytes == 0:
-            raise _lib.C2MError(f"conv3x3: unsupported channel counts Cin={Ci}, Cout={Co}" + (" for the Winograd kernel" if wino else
+            raise _lib.C2MError(f"conv3x3: unsupported channel counts Cin={Ci}, Cout={Co}" + (" for this kernel" if wino else
                                 " (input channels must be a multiple of 32)"))
         if wr is None:
-            wr = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            wr = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            fn = (L.c2m_conv3x3_relayout_f32, L.c2m_conv3x3_relayout_wino_f32, L.c2m_conv3x3_relayout_wino4_f32)[wino]
-            _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
+            if wino in (3, 4):
+                _lib.check(L.c2m_conv3x3_relayout_split_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
+                           "c2m_conv3x3_relayout_split_f32")
+            else:
+                fn = (L.c2m_conv3x3_relayout_f32, L.c2m_conv3x3_relayout_wino_f32, L.c2m_conv3x3_relayout_wino4_f32)[wino]
+                _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
         return wr
 
-    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3) layout
+    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3), 3 split-bf16x3, 4 bf16
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
         slot = (id(weight), rows, wino)
         hit = self._lookup(slot, key, weight)
@@ -360,6 +368,14 @@ import os as _os
 
 _WINO = _os.environ.get("C2M_CONV_WINO", "1") != "0"
 _WINO4 = _os.environ.get("C2M_CONV_WINO4", "1") != "0"
+# C2M_CONV_SPLIT: "1" (default) -- convolutions called with fast=True (decoder, DCN heads, VGG taps of the Ref) run on the
+# split-bf16 kernel (csrc/conv3x3_split.hip: fp32-accurate, 6 bf16 MFMAs per fp32 product sum); "all" -- every convolution,
+# the extractor towers that feed the index search included; "0" -- never (fp32-MFMA direct / Winograd kernels only)
+_SPLIT = _os.environ.get("C2M_CONV_SPLIT", "1")
+ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4}
+_FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16")
+# matrix flops actually executed per algorithmic (direct-convolution) flop, and the pipe they run on
+_EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0)
 
 
 def _wino_ok(srcs, weight, out_mode, W):
@@ -373,6 +389,12 @@ def _wino4_ok(srcs, weight, out_mode, W):
     return _WINO4 and W % 64 == 0 and out_mode == "nhwc" and _wino_ok(srcs, weight, out_mode, W)
 
 
+def _split_ok(srcs, weight, fast):
+    """Split-bf16 kernel: any map size / output mode; 16-channel chunks; sources add up to the weight's input channels."""
+    return ((_SPLIT == "all" or (fast and _SPLIT != "0")) and all(s.shape[1] % 16 == 0 for s in srcs) and
+            sum(s.shape[1] for s in srcs) == weight.shape[1])
+
+
 def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,
             out2_grouped8=None, fast=False):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
@@ -383,20 +405,26 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     "nhwc_pool2" -> channels_last [B,Cout,H/2,W/2] = MaxPool2d(2, 2) of the activated output (Winograd F(2,3) shapes only).
     out2_grouped8: a zero-bordered group-major buffer [B,Cout/8,H+3,W+3,8] that receives a second copy of the output
     (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only.
-    algo: None (auto: Winograd F(2,3) where the shapes allow, else direct), "direct", "winograd", "winograd4".  fast=True lets
-    the auto choice take the F(4,3) kernel (2x fewer matrix instructions, ~4x the rounding error of the direct kernel, still
-    ~1e-6 relative): the decoder asks for it, the extractors that feed the index search do not."""
+    algo: None (auto), "direct", "winograd", "winograd4", "split" (fp32-accurate on the bf16 matrix pipe: three exact bf16
+    pieces per operand, six MFMAs per product sum, csrc/conv3x3_split.hip), "bf16" (one rounded piece: a bf16 convolution
+    with fp32 accumulation).  Auto: fast=True takes the split kernel (any shape / mode; $C2M_CONV_SPLIT=0 restores the
+    round-2 choice: Winograd F(4,3) / F(2,3) / direct on fp32 MFMA); without fast -- the extractor towers that feed the index
+    search -- the fp32-MFMA kernels (F(2,3) where the shapes allow, else direct) unless $C2M_CONV_SPLIT=all."""
     srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
     B, _, H, W = srcs[0].shape
     Cin = sum(s.shape[1] for s in srcs)
     Cout = weight.shape[0]
     dev = srcs[0].device
     if algo is None:
-        wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
+        if (out2_grouped8 is None and _split_ok(srcs, weight, fast) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
+                and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
+            wino = 3
+        else:
+            wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
-        wino = {"direct": 0, "winograd": 1, "winograd4": 2}[algo]
+        wino = ALGO_IDS[algo]
     if out2_grouped8 is not None:
-        if algo in ("winograd", "winograd4") or out_mode != "nhwc":
+        if algo not in (None, "direct") or out_mode != "nhwc":
             raise _lib.C2MError("out2_grouped8 needs the direct kernel in nhwc mode")
         wino = 0
     wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None, wino=wino)
@@ -432,8 +460,8 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         o = _nhwc_src(out, "out")
         d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
     elif out_mode == "nhwc_pool2":
-        if wino != 1 or H % 2 != 0 or W % 2 != 0:
-            raise _lib.C2MError("conv3x3: the pooled epilogue needs the Winograd F(2,3) kernel and even H, W")
+        if wino not in (1, 3, 4) or H % 2 != 0 or W % 2 != 0:
+            raise _lib.C2MError("conv3x3: the pooled epilogue needs the Winograd F(2,3) or the split-bf16 kernel and even H, W")
         out = empty_nhwc(B, Cout, H // 2, W // 2, dev)
         d.out_mode = 4
         o = _nhwc_src(out, "out")
@@ -447,8 +475,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     if _ConvFlops.enabled:
-        _ConvFlops.add(("direct", "winograd_f23", "winograd_f43")[wino], 2.0 * Cout * 9 * Cin * H * W * B,
-                       2.0 * Cout * (9, 6, 4.5)[wino] * Cin * H * W * B)
+        _ConvFlops.add(_FAMILY[wino], 2.0 * Cout * 9 * Cin * H * W * B, 2.0 * Cout * 9 * Cin * H * W * B * _EXEC_FACTOR[wino])
     return out
 
 
@@ -508,7 +535,7 @@ def index_to_flow(max_idx):
     return flow
 
 
-def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, abs_sum=None):
+def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, abs_sum=None, algo=None):
     """The DCN offset/mask head (conv_offset_mask of DCN_sep_pre_multi_offset, dcn_v2.py:229-245) fused with the
     pre-offset construction: -> (offset [B,2*dg*9,H,W], mask [B,dg*9,H,W]) planar, ready for dcn_v2_forward.
     flow: index_to_flow(max_idx) of the matched LR features (or None: no pre-offset); scale = H / h (1, 2, 4).
@@ -533,9 +560,14 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
     split = (Cout // 64) * 64
     slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
+    use_split = algo == "split" or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
+    fam = []
     for (c0, c1) in slices:
-        # 64-channel-tileable slices on whole 32-pixel tiles take the Winograd kernel (1.5x fewer matrix instructions)
-        wino = _WINO and (c1 - c0) % 64 == 0 and W % 32 == 0 and all(s_.shape[1] % 16 == 0 for s_ in srcs)
+        # split-bf16 kernel (any shape); else 64-channel-tileable slices on whole 32-pixel tiles take the Winograd F(2,3)
+        # kernel (1.5x fewer matrix instructions), the rest the direct kernel
+        wino = 3 if use_split else int(_WINO and algo is None and (c1 - c0) % 64 == 0 and W % 32 == 0 and
+                                       all(s_.shape[1] % 16 == 0 for s_ in srcs))
+        fam.append(wino)
         wr = _wcache.get(weight, rows=(c0, c1), wino=wino)
         d = _lib.Conv3x3Desc()
         d.algo = wino
@@ -554,10 +586,9 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     if _ConvFlops.enabled:
-        for (c0, c1) in slices:
-            w_ = _WINO and (c1 - c0) % 64 == 0 and W % 32 == 0
-            _ConvFlops.add("dcn_head_f23" if w_ else "dcn_head_direct", 2.0 * (c1 - c0) * 9 * Cin * H * W * B,
-                           2.0 * (c1 - c0) * (6 if w_ else 9) * Cin * H * W * B)
+        for (c0, c1), w_ in zip(slices, fam):
+            _ConvFlops.add("dcn_head_" + _FAMILY[w_], 2.0 * (c1 - c0) * 9 * Cin * H * W * B,
+                           2.0 * (c1 - c0) * 9 * Cin * H * W * B * _EXEC_FACTOR[w_])
     return offset, mask
 
 
@@ -704,7 +735,7 @@ def _pool_is_2x2(m):
     return two(m.kernel_size) and two(m.stride) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) and not m.ceil_mode
 
 
-def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, grouped8_taps=()):
+def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, grouped8_taps=(), fast=False):
     """Run an ordered {name: nn.Conv2d(3x3, pad 1) | nn.ReLU | nn.MaxPool2d(2, 2)} stack (torchvision's vgg `features`
     layout, mmsr/models/archs/vgg_arch.py:107-123) on the fused channels-last convolution: every conv + its ReLU is one
     launch.  x: [B,3,H,W] image; (x - mean) / std is applied while the image is widened to the kernel's 32-channel chunk.
@@ -712,7 +743,9 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
     channels-last buffers (logical NCHW views of their interiors are returned: the DCNv2 gathers and the offset
     convolutions of the decoder read those buffers in place).  last_nchw: the final layer's output as a contiguous NCHW
     tensor under the key of that layer (the correlation kernels read planar features).  grouped8_taps: taps that also get
-    the group-major twin (BorderedNHWC.grouped8) a DCNv2 layer with 8-channel deformable groups gathers from."""
+    the group-major twin (BorderedNHWC.grouped8) a DCNv2 layer with 8-channel deformable groups gathers from.  fast: as in
+    conv3x3 (the split-bf16 kernel for every layer but the first): the VGG taps of the Ref do, the extractor towers that feed
+    the index search do not."""
     names = list(layers.keys())
     B, C, H, W = x.shape
     dev = x.device
@@ -734,7 +767,7 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
         if k_ == 0 and rgb64:
             kw.pop("algo", None)
             return conv3x3_rgb64(src, layer_.weight, layer_.bias, mean=mean, std=std, **kw)
-        return conv3x3(src, layer_.weight, layer_.bias, **kw)
+        return conv3x3(src, layer_.weight, layer_.bias, fast=fast, **kw)
 
     while k < len(names):
         name, layer = names[k], layers[names[k]]
@@ -749,9 +782,10 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
             Bc, _, Hc, Wc = cur.shape
             nxt = layers[names[k + 2]] if (relu and k + 2 < len(names)) else None
             pool = (isinstance(nxt, torch.nn.MaxPool2d) and _pool_is_2x2(nxt) and tap_name is None and not (k == 0 and rgb64) and
-                    Hc % 2 == 0 and Wc % 2 == 0 and _wino_ok([cur], layer.weight, "nhwc_pool2", Wc))
+                    Hc % 2 == 0 and Wc % 2 == 0 and
+                    (_wino_ok([cur], layer.weight, "nhwc_pool2", Wc) or _split_ok([cur], layer.weight, fast)))
             if last and last_nchw:
-                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out_mode="nchw")
+                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU if relu else ACT_NONE, out_mode="nchw", fast=fast)
                 out[names[k + 1] if relu else name] = cur
             elif tap_name is not None:
                 bo = _bordered_empty(Bc, layer.out_channels, Hc, Wc, dev, grouped8=tap_name in grouped8_taps)
@@ -761,7 +795,7 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
                 out[tap_name] = view
                 cur = view
             elif pool:   # conv -> ReLU -> MaxPool2d(2, 2) in one launch: only the pooled map is written
-                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU, out_mode="nhwc_pool2")
+                cur = conv3x3(cur, layer.weight, layer.bias, act=ACT_RELU, out_mode="nhwc_pool2", fast=fast)
                 k += 1   # (the pool layer)
             else:
                 cur = conv(k, cur, layer, act=ACT_RELU if relu else ACT_NONE)

@@ -90,6 +90,9 @@ class CorrespondenceGenerationArch(nn.Module):
         # deformable groups (ref_restoration_arch.py:73-76, 176-180), i.e. 8-channel groups -- its producer also writes the
         # group-major copy that DCNv2 geometry gathers from (ops.BorderedNHWC.grouped8).  Unused by any other consumer.
         self.vgg.grouped8_taps = ('relu1_1',)
+        # these taps are warped by DCNv2, they do not feed the index search: their convolutions may run on the split-bf16
+        # kernel (fp32-accurate on the bf16 matrix pipe, c2m_amd.ops.conv3x3(fast=True)) like the decoder's
+        self.vgg.fast_conv = True
 
     def index_to_flow(self, max_idx):
         """(h, w) int64 index map of ONE sample -> [1, h+2, w+2, 2] flow (x, y), zero-padded bottom/right

@@ -133,7 +133,7 @@ class VGGFeatureExtractor(nn.Module):
             return _ops.vgg_stack_forward(self.vgg_net._modules, x, taps=self.layer_name_list,
                                           mean=self.mean if self.use_input_norm else None,
                                           std=self.std if self.use_input_norm else None,
-                                          grouped8_taps=getattr(self, 'grouped8_taps', ()))
+                                          grouped8_taps=getattr(self, 'grouped8_taps', ()), fast=getattr(self, 'fast_conv', False))
         if self.use_input_norm:
             x = (x - self.mean) / self.std
         taps = {}

@@ -192,7 +192,7 @@ typedef struct c2m_conv_src {
   long long img_pitch;   /* floats between samples */
 } c2m_conv_src;
 
-enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2 };
+enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2, C2M_CONV_SPLIT_BF16X3 = 3, C2M_CONV_BF16 = 4 };
 enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3, C2M_OUT_NHWC_MAXPOOL2 = 4 };
 
 typedef struct c2m_conv3x3_desc {
@@ -224,7 +224,13 @@ typedef struct c2m_conv3x3_desc {
                               C2M_CONV_WINOGRAD_F43X (2): Winograd F(4,3) along x -- 2x fewer matrix instructions; NHWC mode only,
                               Cout % 64 == 0, W % 64 == 0, channels % 16 == 0, `wr` from c2m_conv3x3_relayout_wino4_f32; its
                               transforms put the result ~4x further from the exact value than the direct kernel (still
-                              ~1e-6 relative): meant for the decoder, not for the extractors that feed the index search */
+                              ~1e-6 relative): meant for the decoder, not for the extractors that feed the index search.
+                              C2M_CONV_SPLIT_BF16X3 (3): fp32 result on the BF16 matrix pipe -- every operand is split exactly into
+                              three bf16 pieces and six piece products are accumulated in fp32 (csrc/conv3x3_split.hip): 6/16 of
+                              the fp32-MFMA time, error below an fp32 fmaf chain; any out_mode (C2M_OUT_NHWC_MAXPOOL2 included),
+                              any H, W, channels % 16 == 0, no out2; `wr` from c2m_conv3x3_relayout_split_f32(pieces = 3).
+                              C2M_CONV_BF16 (4): the same kernel with one round-to-nearest bf16 piece per operand -- a plain bf16
+                              convolution with fp32 accumulation (bf16 inference, BASELINE configs[4]); pieces = 1 */
   int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
   int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
                               head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
@@ -241,6 +247,8 @@ size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout);   /* 0 if unsupported
 int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout);  /* 0 if unsupported (Cin % 16, Cout % 64) */
 int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
+size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3 or 1; 0 if unsupported (Cin % 16) */
+int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
 
 /*

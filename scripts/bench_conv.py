@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--fast", action="store_true", help="let ops.conv3x3 take the Winograd F(4,3) kernel (decoder setting)")
+    ap.add_argument("--fast", action="store_true", help="fast=True: the decoder's setting (split-bf16 kernel; with C2M_CONV_SPLIT=0 the "
+                                                        "Winograd F(4,3) kernel where the map allows)")
+    ap.add_argument("--algo", type=str, default=None, help="force direct / winograd / winograd4 / split / bf16")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -44,20 +46,28 @@ def main():
 
         def run():
             if mode == "head":
-                return ops.conv3x3_dcn_head(xs, w, b, 8, flow, hw // 160)
+                return ops.conv3x3_dcn_head(xs, w, b, 8, flow, hw // 160, algo=args.algo)
             if mode == "nhwc_res":   # second conv of a ResidualBlockNoBN: no activation, + identity
-                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0], fast=args.fast)
-            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode, fast=args.fast)
-        for _ in range(2):
-            run()
+                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0], fast=args.fast, algo=args.algo)
+            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode, fast=args.fast, algo=args.algo)
         c2m_amd.profile_enable(True)
         c2m_amd.profile_collect()
-        for _ in range(args.iters):
-            run()
+        try:
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            c2m_amd.profile_collect()
+            for _ in range(args.iters):
+                run()
+        except c2m_amd.C2MError as e:
+            print({"layer": name, "skipped": str(e)}, flush=True)
+            c2m_amd.profile_collect()
+            c2m_amd.profile_enable(False)
+            continue
         torch.cuda.synchronize()
         ms = [t for (n, t) in c2m_amd.profile_collect() if n == "conv3x3_mfma"]
         c2m_amd.profile_enable(False)
-        ms = sum(ms) / len(ms)
+        ms = sum(ms) / args.iters    # per call (a DCN head is two launches)
         fl = 2.0 * co * 9 * sum(cins) * hw * hw * B
         out.append({"layer": name, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1), "frac_fp32_mfma_peak": round(fl / ms / 1e9 / 157.3, 3)})
         print(out[-1], flush=True)

@@ -234,9 +234,7 @@ def test_conv3x3_winograd_f43_matches_fp64(ops, dev, case):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     tol = 2e-5 * max(1.0, float(want.abs().max()))
     assert float((got.double() - want).abs().max()) < tol
-    auto = ops.conv3x3(xs, w, b, fast=True, **kw)          # the automatic choice with fast=True is this kernel
-    assert torch.equal(auto, got)
-    plain = ops.conv3x3(xs, w, b, **kw)                    # ... and without it the F(2,3) kernel
+    plain = ops.conv3x3(xs, w, b, **kw)                    # the automatic choice without fast=True: the F(2,3) kernel
     assert float((plain.double() - want).abs().max()) < tol
 
 
@@ -294,3 +292,130 @@ def test_conv3x3_winograd_matches_fp64_and_direct(ops, dev, case):
     assert float((got.double() - want).abs().max()) < 2e-5 * scale
     assert float((got - direct).abs().max()) < 2e-5 * scale
     assert float((direct.double() - want).abs().max()) < 1e-5 * scale
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# split-bf16 kernel (csrc/conv3x3_split.hip): fp32 operands split exactly into three bf16 pieces, six piece products per
+# product sum on the bf16 matrix pipe.  Held to the DIRECT kernel's tolerance (1e-5 * scale against float64).
+# ---------------------------------------------------------------------------------------------------------------------
+SPLIT_CASES = [c for c in CASES if c[2] % 4 == 0] + WINO_CASES + [   # (Cout = 3: planar output only, see the modes test)
+    (1, [16], 64, 8, 32, 0, 0),          # one chunk: prologue only, no steady state
+    (1, [32], 64, 3, 5, 1, 0),           # map smaller than a tile
+    (2, [48, 16], 96, 17, 33, 2, 1),     # 16-channel source boundary inside the stream, Cout = 64 + 32 (ragged cout block)
+    (1, [64], 64, 64, 96, 1, 1),         # 24 tiles: several workgroups with several tiles each
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv3x3_split_matches_fp64_conv2d(ops, dev, case):
+    B, cins, Cout, H, W, act, nres = case
+    xs = [_cl(_rand((B, c, H, W), dev, 210 + k)) for k, c in enumerate(cins)]
+    w = _rand((Cout, sum(cins), 3, 3), dev, 220, 1.0 / np.sqrt(9 * sum(cins)))
+    b = _rand((Cout,), dev, 221)
+    res = [_cl(_rand((B, Cout, H, W), dev, 230 + k)) for k in range(nres)]
+    kw = dict(act=act, slope=0.1, res1=res[0] if nres > 0 else None, res2=res[1] if nres > 1 else None)
+    got = ops.conv3x3(xs, w, b, algo="split", **kw)
+    want = _ref(xs, w, b, act, 0.1, res)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got.double() - want).abs().max())
+    assert err < 1e-5 * scale, err
+    auto = ops.conv3x3(xs, w, b, fast=True, **kw)          # the automatic choice with fast=True is this kernel
+    assert torch.equal(auto, got)
+
+
+def test_conv3x3_split_is_at_least_as_accurate_as_the_fp32_mfma_kernels(ops, dev):
+    """The six dropped-term-free piece products put the result closer to float64 than an fp32 fmaf chain of the same length
+    (K = 9 * 256): the split kernel's error must not exceed the direct kernel's by more than a rounding unit."""
+    x = _cl(_rand((1, 256, 24, 64), dev, 300))
+    w, b = _rand((256, 256, 3, 3), dev, 301, 1.0 / 48.0), _rand((256,), dev, 302)
+    want = _ref([x], w, b, 0, 0.0, [])
+    errs = {a: float((ops.conv3x3(x, w, b, algo=a).double() - want).abs().max()) for a in ("direct", "winograd", "split")}
+    assert errs["split"] <= 1.5 * errs["direct"] + 1e-7 and errs["split"] < errs["winograd"] + 1e-7, errs
+
+
+def test_conv3x3_split_output_modes(ops, dev):
+    """PixelShuffle(2), planar NCHW, ReLU + MaxPool2d(2, 2), a channel-slice source and a strided (bordered) destination."""
+    x = _cl(_rand((2, 64, 24, 40), dev, 304))
+    w, b = _rand((256, 64, 3, 3), dev, 305, 0.05), _rand((256,), dev, 306)
+    got = ops.conv3x3(x, w, b, act=ops.ACT_LRELU, slope=0.1, out_mode="pixel_shuffle", algo="split")
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double(), padding=1), 2), 0.1)
+    assert tuple(got.shape) == (2, 64, 48, 80)
+    assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    w3, b3 = _rand((3, 64, 3, 3), dev, 307, 0.05), _rand((3,), dev, 308)
+    got = ops.conv3x3(x, w3, b3, out_mode="nchw", algo="split")
+    want = F.conv2d(x.double(), w3.double(), b3.double(), padding=1)
+    assert got.is_contiguous() and float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    for (B, C, Co, H, W) in ((2, 64, 64, 12, 64), (1, 128, 128, 22, 90), (1, 64, 32, 8, 6)):
+        xp = _cl(_rand((B, C, H, W), dev, 310))
+        wp, bp = _rand((Co, C, 3, 3), dev, 311, 1.0 / np.sqrt(9 * C)), _rand((Co,), dev, 312)
+        got = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, out_mode="nhwc_pool2", algo="split")
+        plain = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, algo="split")
+        assert got.shape == (B, Co, H // 2, W // 2) and torch.equal(got, F.max_pool2d(plain, 2, 2))
+    big = _cl(_rand((2, 128, 24, 40), dev, 313))
+    xs = big[:, 32:96]
+    w2, b2 = _rand((64, 64, 3, 3), dev, 314, 0.05), _rand((64,), dev, 315)
+    bo = ops._bordered_empty(2, 64, 24, 40, dev)
+    view = bo.interior()
+    ops.conv3x3(xs, w2, b2, out=view, algo="split")
+    want = _ref([xs], w2, b2, 0, 0.1, [])
+    assert float((view.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, :, 41:].abs().max()) == 0
+
+
+def test_conv3x3_bf16_single_piece_is_a_bf16_convolution(ops, dev):
+    """algo="bf16": one round-to-nearest bf16 piece per operand, fp32 accumulation -- equal (to fp32 summation error) to a
+    float64 convolution of the bf16-rounded tensors, and ~2^-8 relative away from the fp32 result."""
+    x = _cl(_rand((2, 64, 20, 48), dev, 320))
+    w, b = _rand((64, 64, 3, 3), dev, 321, 1.0 / 24.0), _rand((64,), dev, 322)
+    got = ops.conv3x3(x, w, b, act=ops.ACT_RELU, algo="bf16")
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()
+    want = F.conv2d(xb, wb, b.double(), padding=1).relu()
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) < 1e-5 * scale
+    full = F.conv2d(x.double(), w.double(), b.double(), padding=1).relu()
+    rel = float((got.double() - full).norm() / full.norm())
+    assert 1e-4 < rel < 1e-2, rel
+
+
+def test_dcn_head_on_the_split_kernel(ops, dev):
+    """DCN offset/mask head epilogue of the split kernel (192 + 24 channels): same check as the fp32-MFMA kernels'."""
+    import c2m_oracle as oracle
+    import synth
+    B, C, dg = 2, 64, 8
+    for (h, w, s) in ((12, 14, 1), (12, 16, 2), (12, 16, 4)):
+        H, W = h * s, w * s
+        feat = _cl(_rand((B, C, H, W), dev, 360 + s))
+        wt, bs = _rand((3 * dg * 9, C, 3, 3), dev, 361, 0.02), _rand((3 * dg * 9,), dev, 362, 0.1)
+        hp, wp = h - 2, w - 2
+        idx = (synth.uniform((B, hp, wp), 363, 0.0, 1.0).astype(np.float64) * (hp * wp)).astype(np.int64) % (hp * wp)
+        flow = ops.index_to_flow(torch.from_numpy(idx).to(dev))
+        abs_sum = torch.zeros(256, dtype=torch.float64, device=dev)
+        off, msk = ops.conv3x3_dcn_head(feat, wt, bs, dg, flow, s, abs_sum, algo="split")
+        raw = F.conv2d(feat.double(), wt.double(), bs.double(), padding=1)
+        o1, o2, m = torch.chunk(raw, 3, dim=1)
+        want_off = torch.cat((o1, o2), 1)
+        pre = np.stack([oracle.build_pre_offsets(idx[b], h, w)[{1: 0, 2: 1, 4: 2}[s]] for b in range(B)])
+        pre_t = torch.from_numpy(pre).to(dev).double().flip(-1).permute(0, 1, 4, 2, 3).reshape(B, 18, H, W).repeat(1, dg, 1, 1)
+        want_abs = float(want_off.abs().sum())
+        tol = 1e-5 * max(1.0, float(raw.abs().max()))
+        assert float((off.double() - (want_off + pre_t)).abs().max()) < tol
+        assert float((msk.double() - torch.sigmoid(m)).abs().max()) < 1e-6
+        assert abs(float(abs_sum.sum()) - want_abs) < 1e-4 * want_abs
+
+
+def test_weight_cache_refresh_follows_data_writes(ops, dev):
+    """`w.data.copy_()` does not bump `_version`; ops.refresh_weight_caches() (called by the fused forwards once per
+    call) rebuilds the cached weight images from the tensor's current contents."""
+    x = _cl(_rand((1, 32, 8, 8), dev, 350))
+    w = torch.nn.Parameter(_rand((32, 32, 3, 3), dev, 351, 0.1))
+    for algo in ("direct", "split"):
+        a = ops.conv3x3(x, w, algo=algo)
+        v0 = w._version
+        w.data.mul_(2.0)
+        assert w._version == v0
+        assert ops.refresh_weight_caches([w]) >= 1
+        b2 = ops.conv3x3(x, w, algo=algo)
+        assert float((b2 - 2 * a).abs().max()) < 1e-5 * float(a.abs().max())
+        w.data.mul_(0.5)
+        ops.refresh_weight_caches([w])
