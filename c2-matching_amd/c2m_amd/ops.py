@@ -368,10 +368,11 @@ import os as _os
 
 _WINO = _os.environ.get("C2M_CONV_WINO", "1") != "0"
 _WINO4 = _os.environ.get("C2M_CONV_WINO4", "1") != "0"
-# C2M_CONV_SPLIT: "1" (default) -- convolutions called with fast=True (decoder, DCN heads, VGG taps of the Ref) run on the
-# split-bf16 kernel (csrc/conv3x3_split.hip: fp32-accurate, 6 bf16 MFMAs per fp32 product sum); "all" -- every convolution,
-# the extractor towers that feed the index search included; "0" -- never (fp32-MFMA direct / Winograd kernels only)
-_SPLIT = _os.environ.get("C2M_CONV_SPLIT", "1")
+# C2M_CONV_SPLIT: "all" (default) -- every convolution the split-bf16 kernel supports runs on it (csrc/conv3x3_split.hip:
+# fp32-accurate, 6 bf16 MFMAs per fp32 product sum), the extractor towers that feed the index search included (measured on
+# configs[2]: 1 near-tie flip of 24 964 queries against the CPU chain, 2 with the fp32-MFMA kernels); "1" -- only calls
+# with fast=True (decoder, DCN heads, VGG taps of the Ref); "0" -- never (fp32-MFMA direct / Winograd kernels only)
+_SPLIT = _os.environ.get("C2M_CONV_SPLIT", "all")
 ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4}
 _FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16")
 # matrix flops actually executed per algorithmic (direct-convolution) flop, and the pipe they run on
@@ -407,9 +408,10 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only.
     algo: None (auto), "direct", "winograd", "winograd4", "split" (fp32-accurate on the bf16 matrix pipe: three exact bf16
     pieces per operand, six MFMAs per product sum, csrc/conv3x3_split.hip), "bf16" (one rounded piece: a bf16 convolution
-    with fp32 accumulation).  Auto: fast=True takes the split kernel (any shape / mode; $C2M_CONV_SPLIT=0 restores the
-    round-2 choice: Winograd F(4,3) / F(2,3) / direct on fp32 MFMA); without fast -- the extractor towers that feed the index
-    search -- the fp32-MFMA kernels (F(2,3) where the shapes allow, else direct) unless $C2M_CONV_SPLIT=all."""
+    with fp32 accumulation).  Auto: the split kernel wherever it applies (any map size / mode, channels % 16 == 0).
+    $C2M_CONV_SPLIT=1 restricts it to calls with fast=True (the decoder; the extractor towers that feed the index search
+    then stay on the fp32-MFMA kernels), $C2M_CONV_SPLIT=0 restores the round-2 choice everywhere: Winograd F(4,3) with
+    fast=True / F(2,3) where the shapes allow, else direct."""
     srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
     B, _, H, W = srcs[0].shape
     Cin = sum(s.shape[1] for s in srcs)

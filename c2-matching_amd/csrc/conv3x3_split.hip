@@ -114,21 +114,60 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float
   wr[e0] = bf16_piece(v, pl, NP == 1);
 }
 
-template <int NP, int MT, int MODE>
-__global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
+// compile-time loop and LDS instructions with immediate offsets (hand-placed: hipcc re-uses operand registers and then
+// issues the next tap's reads behind the last MFMA that reads them -- one exposed LDS latency per tap)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read128(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read128f(f32x4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
+}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor as four SGPR words (stride 0, bounds-checked: out-of-range lanes read zeros)
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+template <int IMM>
+__device__ __forceinline__ void buf_load128(bf16x8& d, unsigned voff, const i32x4 rsrc, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void buf_load128f(f32x4& d, unsigned voff, const i32x4 rsrc, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
+}
+
+// ABL > 0: timing-only ablations (WRONG results; $C2M_SPLIT_ABL): 1 no weight DMA after the prologue, 2 no halo DMA, 3 no
+// split of the raw tile, 4 no unit-end waits / barriers, 5 no MFMAs, 6 no operand reads, 7 MFMAs + barriers only, 8 MFMAs only
+template <int NP, int MT, int MODE, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   constexpr int NT = 2;
   constexpr int MW = 32 * MT;
   using PR = Products<NP>;
   constexpr int PLB = NP * 2 * HALFB;           // bytes of one plane buffer
   constexpr int WTAP = NP * MT * 1024;          // one tap's weight image: [plane][mt][half][32 rows][16 B]
-  constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
-  constexpr int NWI = WUNIT / 1024;             // DMA instructions per unit
-  constexpr int NW_W = (NWI + 3) / 4;           // per wave (the last wave pads with dummies: uniform vmcnt counts)
+  constexpr int WUNIT = 3 * WTAP;               // one kernel row
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  // [raw | planes x2 | weight ring x3 | dummy 1 KiB | bias MW floats]
+  // [planes x2 | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned raw_base = lds0, pl_base = lds0 + RAW_BYTES, w_base = pl_base + 2 * PLB, dummy = w_base + 3 * WUNIT,
-                 bias_lds = dummy + 1024;
+  const unsigned pl_base = lds0, bias_lds = lds0 + 2 * PLB;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,25 +177,29 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
   const int cb = blockIdx.y;
   const int UT = p.nchunks * 3;         // units per tile
   const int G = ntl * p.nchunks;        // chunks of this workgroup
-  const int T = G * 3;                  // units of this workgroup
 
-  // ---- weights: unit u of this cout block = WUNIT contiguous bytes; wave w moves instructions [w*NW_W, (w+1)*NW_W)
-  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
-  const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
-  int wsoff = 0;
-  auto issue_w = [&](int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NW_W; ++i) {
-      const int n = wv * NW_W + i;
-      const unsigned dst = n < NWI ? w_base + slot * WUNIT + n * 1024 : dummy;
-      // (beyond the image: reads the next unit / zeros past the end of the buffer, lands in the dummy page)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff + i * 1024, 0, 0);
-    }
-    wsoff += WUNIT;
+  // ---- weights: never staged in LDS.  The A operand of (chunk, dy, dx, plane, mt) is 1 KiB contiguous in the re-laid-out
+  // weights (lane (hi, j): 16 bytes at hi*512 + j*16): one buffer_load_dwordx4 per operand straight into the registers the
+  // MFMA reads, issued TWO taps ahead of its use (LDS-DMA costs ~100 issue cycles per KiB on this chip -- with one wave per
+  // SIMD that is matrix time -- and the weight stream is 70 % of this kernel's fills).  The four waves read the same
+  // lines: one L2 fetch, three L1 hits.  soffset = byte offset of the tap inside this cout block's weights (wraps per tile).
+  const i32x4 wrs = make_rsrc_words(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
+  const unsigned wvoff0 = hi * 512 + j * 16, wvoff1 = wvoff0 + 4096;
+  int wsoff = 0;   // tap the NEXT load_a() call fetches
+  bf16x8 A[3][NP][MT], Bq[3][NP][NT];   // operand sets, one per kernel column dx
+  auto load_a_piece = [&](auto dxc, auto kc) __attribute__((always_inline)) {   // operand K = pl*MT + mt of the tap at wsoff -> set DX
+    constexpr int DX = decltype(dxc)::value, K = decltype(kc)::value;
+    if constexpr (K < 4) buf_load128<K * 1024>(A[DX][K / MT][K % MT], wvoff0, wrs, wsoff);
+    else buf_load128<(K - 4) * 1024>(A[DX][K / MT][K % MT], wvoff1, wrs, wsoff);
+  };
+  auto load_a_done = [&]() __attribute__((always_inline)) {
+    wsoff += WTAP;
     if (wsoff == UT * WUNIT) wsoff = 0;
   };
 
-  // ---- halo tile: instruction n = wave + 4 * slot covers pieces [64n, 64n + 64); piece P = (pixel P >> 2, channel quad P & 3)
+  // ---- halo tile: 24 slots of 64 pieces (pixel, 4 fp32 channels); slot r of wave wv = pieces [64 (wv + 4r), +64), fetched
+  // by buffer_load_dwordx4 (hardware zero fill outside the image) into a register that stays with the wave until split round
+  // r of that chunk has consumed it -- a whole chunk later
   struct TileCoord { int b, ty, tx; };
   auto tc_init = [&](int tile) __attribute__((always_inline)) {
     TileCoord t;
@@ -172,10 +215,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
     }
   };
   TileCoord dma_tc = tc_init(tile_first), epi_tc = dma_tc;
-  int dma_c = 0;   // chunk (inside its tile) the next issue_in() call fetches
+  int dma_c = 0;   // chunk (inside its tile) the next issue_in_begin() call fetches
   unsigned ivoff[NRAW_W];
   int ib = 0, iy0 = 0, ix0 = 0;
-  __amdgpu_buffer_rsrc_t rs0, rs1;
+  i32x4 rs0, rs1;
   int slotc[NRAW_W];   // ry | rx << 8 | quad << 16 | valid << 24
 #pragma unroll
   for (int sl = 0; sl < NRAW_W; ++sl) {
@@ -194,11 +237,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
     const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
-    return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
+    return make_rsrc_words(S.ptr + (long long)b * S.img_pitch, bytes);
   };
-  auto issue_in = [&]() __attribute__((always_inline)) {   // the next chunk of the workgroup's stream -> raw
+  int in_soff = 0;
+  bool in_first = true;
+  auto issue_in_begin = [&]() __attribute__((always_inline)) {   // the next chunk of the workgroup's stream
     const int c0 = dma_c * KC;
-    const bool first = c0 < p.src[0].C;
+    in_first = c0 < p.src[0].C;
     if (++dma_c == p.nchunks) dma_c = 0;
     if (c0 == 0) {
       ib = dma_tc.b; iy0 = dma_tc.ty * THY; ix0 = dma_tc.tx * TWX;
@@ -209,57 +254,45 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
     } else if (c0 == p.src[0].C) {
       set_source(p.src[1]);
     }
-    const int soff = (first ? c0 : c0 - p.src[0].C) * 4;
-#pragma unroll
-    for (int sl = 0; sl < NRAW_W; ++sl) {
-      const int n = wv + 4 * sl;
-      const unsigned dst = raw_base + n * 1024;
-      if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dst, 16, ivoff[sl], soff, 0, 0);
-    }
+    in_soff = (in_first ? c0 : c0 - p.src[0].C) * 4;
+  };
+  f32x4 rawr[NRAW_W];
+  auto issue_in_piece = [&](auto slc) __attribute__((always_inline)) {
+    constexpr int sl = decltype(slc)::value;
+    if (in_first) buf_load128f(rawr[sl], ivoff[sl], rs0, in_soff);
+    else buf_load128f(rawr[sl], ivoff[sl], rs1, in_soff);
   };
 
-  // ---- split of the wave's own raw pieces into the bf16 planes of buffer `nb`.  Round r = DMA slot r of this wave:
-  // instruction n = wv + 4r, piece 64n + l = (pixel 16n + (l >> 2), quad q = l & 3) -> plane slab (q >> 1), 8 bytes at
-  // pixel*16 + (q & 1)*8.  Software-pipelined: the raw piece of round r+1 is read while round r is being split.
-  const unsigned craw = raw_base + wv * 1024 + l * 16;                                       // + r * 4096
+  // ---- split of the wave's own raw pieces into the bf16 planes of buffer `nb`.  Round r: piece 64 (wv + 4r) + l =
+  // (pixel 16 (wv + 4r) + (l >> 2), quad q = l & 3) -> plane slab (q >> 1), 8 bytes at pixel*16 + (q & 1)*8.
   const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;   // + r * 1024 + plane * 2*HALFB + nb * PLB
-  auto conv_load = [&](int R) __attribute__((always_inline)) {
-    return *(const __attribute__((address_space(3))) f32x4*)(craw + R * 4096);
-  };
-  auto conv_store = [&](int R, unsigned nb_off, const f32x4 v) __attribute__((always_inline)) {
+  u32x2 cq[3];   // the split pieces of the current round, between the group that forms them and the group that stores them
+  auto conv_split = [&](const f32x4 v) __attribute__((always_inline)) {
     if constexpr (NP == 3) {
-      u32x2 q0, q1, q2;
-      split3(v, q0, q1, q2);
-      *(__attribute__((address_space(3))) u32x2*)(cdst + nb_off + R * 1024) = q0;
-      *(__attribute__((address_space(3))) u32x2*)(cdst + nb_off + R * 1024 + 2 * HALFB) = q1;
-      *(__attribute__((address_space(3))) u32x2*)(cdst + nb_off + R * 1024 + 4 * HALFB) = q2;
+      split3(v, cq[0], cq[1], cq[2]);
     } else {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 h;
 #pragma unroll
       for (int i = 0; i < 4; ++i) h[i] = (__bf16)v[i];   // round to nearest even
-      *(__attribute__((address_space(3))) bf16x4*)(cdst + nb_off + R * 1024) = h;
+      cq[0] = __builtin_bit_cast(u32x2, h);
+    }
+  };
+  auto conv_store = [&](auto rr, unsigned dst) __attribute__((always_inline)) {   // dst = cdst + buffer offset
+    constexpr int R = decltype(rr)::value;
+    lds_write64<R * 1024>(dst, cq[0]);
+    if constexpr (NP == 3) {
+      lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
+      lds_write64<R * 1024 + 4 * HALFB>(dst, cq[2]);
     }
   };
 
-  // ---- operand addresses
-  // A: lane (cout row j, k half hi) of ring slot dy, tap dx, plane pl, channel tile mt: w_base + dy*WUNIT + dx*WTAP + (pl*MT+mt)*1024
-  const unsigned abase = w_base + hi * 512 + j * 16;
-  // B: pixel (row 2wv + nt + dy, column j + dx) of the halo tile, k half hi, plane pl, buffer nb
+  // ---- B operand: pixel (row 2wv + nt + dy, column j + dx) of the halo tile, k half hi, plane pl, buffer nb
   const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
-  // three operand sets, one per kernel column dx: tap (dy, dx) multiplies set dx while set (dx + 1) % 3 is being fetched
-  bf16x8 A[3][NP][MT], Bq[3][NP][NT];
-  auto load_tap = [&](int dy, int dx, unsigned nb_off) __attribute__((always_inline)) {
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        A[dx][pl][mt] = *(const __attribute__((address_space(3))) bf16x8*)(abase + dy * WUNIT + dx * WTAP + (pl * MT + mt) * 1024);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        Bq[dx][pl][nt] = *(const __attribute__((address_space(3))) bf16x8*)(bbase + nb_off + pl * 2 * HALFB + ((nt + dy) * HWc + dx) * 16);
-    }
+  constexpr int NLB = NP * NT, NLA = NP * MT;       // B reads (LDS) / A loads (L1/L2) per tap
+  auto load_b = [&](auto dyc, auto dxc, auto kc, unsigned bsrc) __attribute__((always_inline)) {   // read K of tap (DY, DX) -> set DX
+    constexpr int DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[DX][K / NT][K % NT], bsrc);
   };
 
   const int co_lane = cb * MW + 4 * hi;
@@ -276,91 +309,92 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
   // ------------------------------------------------------------------------------------------------------------------
-  // prologue: chunk 0 is fetched, split and published before the first MFMA
+  // prologue: chunk 0 is fetched, split and published before the first MFMA; the weights of taps 0 and 1 and the raw
+  // pieces of chunk 1 are in flight
   // ------------------------------------------------------------------------------------------------------------------
-  issue_in();
-  issue_w(0);
-  issue_w(1);
-  issue_w(2);
-  wait_vmcnt<0>();
-#pragma unroll
-  for (int R = 0; R < NRAW_W; ++R) conv_store(R, 0u, conv_load(R));
+  issue_in_begin();
+  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
+  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
+    constexpr int R = decltype(rr)::value;
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rawr[R]) : "n"(NRAW_W - 1 - R));
+    conv_split(rawr[R]);
+    conv_store(rr, cdst);
+  });
+  if (G > 1) {
+    issue_in_begin();
+    static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
+  }
+  static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) { load_a_piece(std::integral_constant<int, 0>(), kc); });
+  load_a_done();
+  static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) { load_a_piece(std::integral_constant<int, 1>(), kc); });
+  load_a_done();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (G > 1) issue_in();   // the raw pieces of a wave are private to it: no barrier needed before they are overwritten
   __builtin_amdgcn_s_barrier();
-  load_tap(0, 0, 0u);
-  if (G > 1) wait_vmcnt<0>();   // raw(1): once per workgroup
-  f32x4 rawv = conv_load(0);
+  static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
+    load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, bbase);
+  });
 
-  f32x4 res4[MT][NT][4];
+  // One tap = PR::N groups of MT*NT MFMAs (one piece product each), fenced by sched_barriers so that everything else stays
+  // where it is written.  Per tap: the NLB B reads of the next tap (LDS, first groups), the NLA A loads of the tap after next
+  // (one per group), on six of the nine taps one split round of the next chunk (VALU in the last group but one, its three
+  // stores in the last; the round's register is then re-loaded for the chunk after next).
+  // Waits at the top of a tap: lgkmcnt(0) -- every LDS operation of the previous tap, the youngest a group old; vmcnt(NLA) --
+  // all but the NLA loads issued during the previous tap, i.e. this tap's A operands (issued two taps ago) and every raw
+  // piece older than that.  Two barriers per chunk: after unit 1 (the split planes of the next chunk are complete) and
+  // after unit 2 (everybody has finished reading this chunk's planes: the next chunk may overwrite them).
+  constexpr int NG = PR::N;
+  constexpr int BPG = NG >= 4 ? (NLB + NG - 3) / (NG - 2) : NLB;    // B reads per group
+  constexpr int APG = (NLA + NG - 1) / NG;                          // A loads per group
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       const unsigned nb_cur = (gc & 1) ? PLB : 0u, nb_nxt = PLB - nb_cur;
-      const bool last_chunk = c == p.nchunks - 1;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int u = 3 * gc + dy;
-        if (MODE == 0 && dy == 2 && last_chunk) {   // residuals: their latency runs under the last unit's MFMAs
-          const int b = epi_tc.b, y0 = epi_tc.ty * THY, x0 = epi_tc.tx * TWX;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int y = y0 + 2 * wv + nt, x = x0 + j;
-            const bool pok = y < p.H && x < p.W;
-            const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int qd = 0; qd < 4; ++qd) {
-                f32x4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) {
-                  if (p.res1) rv = *reinterpret_cast<const f32x4*>(p.res1 + opix + co_lane + mt * 32 + 8 * qd);
-                  if (p.res2) rv += *reinterpret_cast<const f32x4*>(p.res2 + opix + co_lane + mt * 32 + 8 * qd);
-                }
-                res4[mt][nt][qd] = rv;
-              }
-          }
-        }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int t = 3 * dy + dx;
-          // the split of the NEXT chunk rides on units 0 and 1 (one round per tap; published by the barrier that ends
-          // unit 1).  Past the end of the stream it splits stale bytes into a buffer nobody reads: branch-free.
-          if (dy < 2) {
-            const f32x4 v = rawv;
-            if (t < 5) rawv = conv_load(t + 1);
-            conv_store(t, nb_nxt, v);
-          }
-          // operands of the next tap (the last tap of a chunk: tap 0 of the next chunk, from the other plane buffer)
-          if (dx < 2) load_tap(dy, dx + 1, nb_cur);
-          else if (dy < 2) load_tap(dy + 1, 0, nb_cur);
-          else load_tap(0, 0, nb_nxt);
-#pragma unroll
-          for (int pr = 0; pr < PR::N; ++pr)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dx][PR::W[pr]][mt], Bq[dx][PR::X[pr]][nt], acc[mt][nt], 0, 0, 0);
-          // spread the tap's LDS traffic and the split's VALU over the MFMA issue gaps
-#pragma unroll
-          for (int k = 0; k < PR::N * MT * NT; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-          }
+      const unsigned bcur = bbase + nb_cur, bnxt = bbase + nb_nxt, cnxt = cdst + nb_nxt;
+      const bool more_in = ABL != 2 && ABL < 7 && gc + 2 < G;   // the raw registers are re-loaded for chunk gc+2 as the rounds of chunk gc+1 free them
+      if (more_in) issue_in_begin();
+      static_for<0, 3>([&](auto dyc) __attribute__((always_inline)) {
+        constexpr int dy = decltype(dyc)::value;
+        static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
+          constexpr int dx = decltype(dxc)::value;
+          constexpr int t = 3 * dy + dx;
+          constexpr bool conv = dy < 2 && ABL != 3 && ABL < 7;   // split round t of the NEXT chunk (units 0 and 1)
+          constexpr int ndx = (dx + 1) % 3, ndy = dx < 2 ? dy : (dy + 1) % 3;   // the next tap
+          constexpr int adx = (dx + 2) % 3;                                      // set of the tap after next
+          const unsigned bsrc = (dx == 2 && dy == 2) ? bnxt : bcur;
+          if constexpr (ABL < 7) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
           __builtin_amdgcn_sched_barrier(0);
-        }
-        if (u + 1 < T) {
-          // own LDS stores (the split) and own DMAs (W(u+2), raw) have landed; then everybody's
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          wait_vmcnt<0>();
+          static_for<0, NG>([&](auto gcnt) __attribute__((always_inline)) {
+            constexpr int g = decltype(gcnt)::value;
+            if constexpr (ABL != 6 && ABL < 7) {
+              static_for<g * BPG, (g + 1) * BPG < NLB ? (g + 1) * BPG : NLB>([&](auto kc) __attribute__((always_inline)) {
+                load_b(std::integral_constant<int, ndy>(), std::integral_constant<int, ndx>(), kc, bsrc);
+              });
+            }
+            if constexpr (ABL != 1 && ABL < 7) {
+              static_for<g * APG, (g + 1) * APG < NLA ? (g + 1) * APG : NLA>([&](auto kc) __attribute__((always_inline)) {
+                load_a_piece(std::integral_constant<int, adx>(), kc);
+              });
+            }
+            if constexpr (conv && g == (NG >= 2 ? NG - 2 : 0)) conv_split(rawr[t < NRAW_W ? t : 0]);
+            if constexpr (conv && g == NG - 1) {
+              conv_store(std::integral_constant<int, (t < NRAW_W ? t : 0)>(), cnxt);
+              if (more_in) issue_in_piece(std::integral_constant<int, (t < NRAW_W ? t : 0)>());   // same slot of the chunk after next
+            }
+            if constexpr (ABL != 5) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dx][PR::W[g]][mt], Bq[dx][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          if constexpr (ABL != 1 && ABL < 7) load_a_done();
+        });
+        if constexpr (dy >= 1 && ABL != 4 && ABL != 8) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own split stores / operand reads are done; then everybody's
           __builtin_amdgcn_s_barrier();
-          if (u + 3 < T) issue_w(dy);                       // unit u+3 = same kernel row of the next chunk -> same ring slot
-          if (dy == 1 && gc + 2 < G) issue_in();            // raw was consumed by the rounds of units 0 and 1
-          if (dy == 2) rawv = conv_load(0);                 // first piece of the chunk after next (landed: vmcnt(0) above)
         }
-      }
+      });
     }
     // ----------------------------------------------------------------------------------------------------------------
     // epilogue of the tile
@@ -452,7 +486,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_split_kernel(Params p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
                 if (co + 3 < p.Cout) {
-                  v += res4[mt][nt][qd];
+                  // (residuals are fetched here: the co-resident workgroup's MFMAs cover the latency)
+                  if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + opix + co);
+                  if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + opix + co);
                   *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
                 } else {
                   for (int e = 0; e < 4 && co + e < p.Cout; ++e) {
@@ -528,13 +564,35 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
-  constexpr size_t ldsb = split::RAW_BYTES + 2 * (size_t)(NP * 2 * split::HALFB) + 3 * (size_t)(3 * NP * MT * 1024) + 1024 + 256;
+  constexpr size_t ldsb = 2 * (size_t)(NP * 2 * split::HALFB) + 256;   // two plane buffers + bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsb, dn)) == C2M_OK)
       hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
   };
+  if constexpr (NP == 3 && MT == 2) {
+    static const int abl = [] {
+      const char* e = getenv("C2M_SPLIT_ABL");
+      const int v = e ? atoi(e) : 0;
+      if (v > 0) fprintf(stderr, "c2m: C2M_SPLIT_ABL=%d -- conv3x3 split kernel runs a timing-only ablation, its results are wrong\n", v);
+      return v;
+    }();
+    static unsigned long long done_abl[9] = {};
+    if (abl > 0 && p.out_mode == 0) {
+      switch (abl) {
+        case 1: go(&split::conv3x3_split_kernel<3, 2, 0, 1>, done_abl[1]); break;
+        case 2: go(&split::conv3x3_split_kernel<3, 2, 0, 2>, done_abl[2]); break;
+        case 3: go(&split::conv3x3_split_kernel<3, 2, 0, 3>, done_abl[3]); break;
+        case 4: go(&split::conv3x3_split_kernel<3, 2, 0, 4>, done_abl[4]); break;
+        case 5: go(&split::conv3x3_split_kernel<3, 2, 0, 5>, done_abl[5]); break;
+        case 6: go(&split::conv3x3_split_kernel<3, 2, 0, 6>, done_abl[6]); break;
+        case 7: go(&split::conv3x3_split_kernel<3, 2, 0, 7>, done_abl[7]); break;
+        default: go(&split::conv3x3_split_kernel<3, 2, 0, 8>, done_abl[8]); break;
+      }
+      return rc;
+    }
+  }
   switch (p.out_mode) {
     case 0: go(&split::conv3x3_split_kernel<NP, MT, 0>, done[0]); break;
     case 1: go(&split::conv3x3_split_kernel<NP, MT, 1>, done[1]); break;
@@ -555,7 +613,7 @@ int launch_split(hipStream_t st, Params p, int np) {
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
   static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
-  const long long resident = 256;   // one workgroup per CU
+  const long long resident = 512;   // two workgroups per CU (75 KiB of LDS, <= 256 registers each)
   long long tpw = 1, best = -1;
   for (long long t = 1; t <= 10; ++t) {
     const long long wgs = ((ntile + t - 1) / t) * ncb;

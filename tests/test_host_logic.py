@@ -300,6 +300,19 @@ def test_conv_algo_selection_is_shape_driven():
     assert not ops._wino_ok(src(64, 64), torch.zeros(32, 64, 3, 3), "nhwc", 64)   # 32 output channels
     assert not ops._wino_ok(src(64, 64), w64, "nchw", 64)
     assert not ops._wino_ok([torch.zeros(1, 24, 8, 64), torch.zeros(1, 40, 8, 64)], w64, "nhwc", 64)   # 24-channel source
+    # split-bf16 kernel: any map size, 16-channel chunks; policy from $C2M_CONV_SPLIT ("all": every call, "1": fast=True only)
+    old = ops._SPLIT
+    try:
+        ops._SPLIT = "all"
+        assert ops._split_ok(src(64, 37), w64, False) and ops._split_ok(src(48, 5), torch.zeros(24, 48, 3, 3), False)
+        assert not ops._split_ok(src(24, 64), torch.zeros(64, 24, 3, 3), True)       # 24 channels: not a whole chunk
+        assert not ops._split_ok(src(32, 64), w64, True)                             # sources do not add up to the weight's Cin
+        ops._SPLIT = "1"
+        assert ops._split_ok(src(64, 37), w64, True) and not ops._split_ok(src(64, 37), w64, False)
+        ops._SPLIT = "0"
+        assert not ops._split_ok(src(64, 37), w64, True)
+    finally:
+        ops._SPLIT = old
 
 
 def test_cpu_chain_mismatch_margins_scores_both_picks():
