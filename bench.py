@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- LR-Ref image pairs / second of the MI355X restoration path on synthetic 160x160-LR / 500x500-Ref pairs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload restore|corr]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload restore|corr|train] [--lr 160] [--dtype f32|bf16]
 
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: "Batch-16 full restoration forward
 (correlation + DCNv2 warp + decoder), 1xMI355X, fp32".  One "step" = one pass over one batch of B=16 pairs per GPU:
@@ -9,19 +9,29 @@ ContrasExtractorSep on the bicubic-upsampled LR and the zero-padded Ref -> chann
 arg-max index map -> pre-offsets -> VGG19 taps of the Ref -> RestorationNet (content extractor, three DynAgg = DCNv2 warps,
 3 x 16 residual blocks, up-sampling tails) -> SR image [16,3,640,640].  Images and weights are resident in HBM before the
 timed region; weights are seeded random (no checkpoints offline), the offset heads are live (N(0, 0.01)).
-`--workload corr` times configs[1] alone (normalise + correlation + pre-offsets on synthetic features).
 
-N>1: launched by torch.distributed.run, one rank per GPU, every rank its own batch (weak scaling, no data-path
-collective: pairs are independent -- SURVEY.md 8e); the barrier / max-over-ranks timing uses RCCL.
+Other workloads: `--workload corr` = configs[1] (normalise + correlation + pre-offsets on synthetic features);
+`--workload train` = configs[3] (stage-3 MSE training step, 4 pairs per GPU, GT 160x160: forward, L1 loss, backward incl. the
+three DCNv2 backward passes, Adam; with N > 1 net_g's gradients are all-reduced by DDP over RCCL);
+`--lr 320 --dtype bf16` = configs[4] (CUFED5-shape inference under bf16 autocast; batch defaults to 4 per GPU).
 
-Prints ONE JSON line (rank 0): the contract fields, `stage_ms`, `roofline` (the hand-written kernel with the largest share
-of the step) + `roofline_kernels` (every hand-written hot kernel: HIP events on the launch stream through c2m_profile_*,
-FLOPs per SURVEY.md 8d), `configs1_corr_only` (the round-1 headline, kept as a sub-record) and `cpu_baseline` (the same
-forward for ONE pair on the host cores through oracle/cpu_chain.py, outside the timed region).
+N > 1: one rank per GPU.  Started as a plain command, bench.py re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the reference's launcher logic is mmsr/train.py:24-45); started by
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank works on its own batch (weak scaling, no
+data-path collective: pairs are independent -- SURVEY.md 8e); barrier / max-over-ranks timing use RCCL.
+
+Prints ONE JSON line (rank 0): the contract fields, `stage_ms`, `roofline` (the hand-written kernel family with the largest
+share of the step) + `roofline_kernels` (every hand-written hot kernel: HIP events on the launch stream through
+c2m_profile_*; `frac` = EXECUTED matrix flops / peak of the pipe they run on, always <= 1; algorithmic-equivalent rates in
+their own keys), `configs1_corr_only` (the round-1 headline, kept as a sub-record) and `cpu_baseline` (the same forward on
+the host cores through oracle/cpu_chain.py, outside the timed region, with the GPU-vs-CPU parity of three pairs of the
+timed batch).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,11 +40,24 @@ for _p in (os.path.join(REPO, "c2-matching_amd"),):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+BF16_SUSTAINED_TFLOPS = 1780.0    # scripts/ubench/mfma_bf16_rate: back-to-back MFMAs on all 1024 SIMDs with non-zero operands
+                                  # (the chip clocks down to ~1.7 GHz under that load: profiles/r03_ubench_mfma_bf16_rate.log)
 HBM_PEAK_GBS = 8000.0
 METRIC = "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)"
+
+
+def _respawn_under_torchrun(args):
+    """`python bench.py --gpus N` as a plain command: start N ranks of this very command line on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -43,6 +66,7 @@ METRIC = "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)"
 def synth_features(B, C, h, valid, dev, seed):
     """N(0,1) features; the ref map carries the constant band a zero-padded 500x500 Ref leaves beyond 125/160
     (ref_cufed_dataset.py:107-114) -> exact ties exist, as in the reference's test-time data."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
     fin = torch.randn((B, C, h, h), generator=g, device=dev, dtype=torch.float32)
     fref = torch.randn((B, C, h, h), generator=g, device=dev, dtype=torch.float32)
@@ -55,20 +79,22 @@ def synth_features(B, C, h, valid, dev, seed):
 
 def synth_images(B, h, dev, seed):
     """img_in_lq ~ U(0,1) [B,3,h,h]; img_in_up = bicubic x4; img_ref ~ U(0,1) 500x500 zero-padded to 4h."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
     lq = torch.rand((B, 3, h, h), generator=g, device=dev)
     up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
     ref = torch.zeros((B, 3, 4 * h, 4 * h), device=dev)
-    v = min(4 * h, (500 * 4 * h) // 640)
+    v = min(4 * h, 500)
     ref[:, :, :v, :v] = torch.rand((B, 3, v, v), generator=g, device=dev)
     return lq, up, ref
 
 
 def build_models(dev, seed=1234):
+    import warnings
+    import torch
     from mmsr.models.archs.contras_extractor_arch import ContrasExtractorSep
     from mmsr.models.archs.corres_generation_arch import CorrespondenceGenerationArch
     from mmsr.models.archs.ref_restoration_arch import RestorationNet
-    import warnings
     torch.manual_seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # "VGG weights are RANDOM": intended here (synthetic benchmark)
@@ -96,90 +122,210 @@ def corr_executed_flops(B, C, h, swept_rows=None):
 
 
 def corr_swept_rows(h):
-    """(rows swept, rows of the full sweep) of the most recent correlation launch, from the kernel's own skip table."""
+    """(rows swept, rows of the full sweep) of the most recent recorded correlation launch, from the kernel's own skip table."""
     from c2m_amd import ops
     tab = ops.last_corr_skip_table().cpu()
     full = tab.shape[0] * tab.shape[1] * h
     return int(full - (tab[..., 1] - tab[..., 0]).sum().item()), full
 
 
-def corr_roofline(B, C, h, kms, n, traffic, swept=None):
+def _tf(flops, ms):
+    return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+
+def corr_roofline(B, C, h, kms, n, pmc, swept=None):
     exec_flops = corr_executed_flops(B, C, h, swept[0] if swept else None)
     useful = B * 2.0 * (h * h) ** 2 * C                      # pixel-level products D[p][r]: the restructured minimum
     algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9             # SURVEY.md 8d: 2*Nq*Nr*C*9 per pair
-    tf = lambda f: f / (kms * 1e-3) / 1e12 if kms > 0 else 0.0  # noqa: E731
-    return {"bound": "mfma", "kernel": f"corr_argmax_mfma_kernel<{C}>", "achieved": tf(exec_flops),
-            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf(exec_flops) / FP32_MATRIX_PEAK_TFLOPS,
-            "traffic": traffic, "kernel_ms": kms, "launches_timed": n,
-            "frac_definition": "executed fp32 MFMA flops / peak (hardware utilisation, <= 1).  SURVEY 8d's algorithmic "
-                               "figure (the reference's conv2d formulation) is 8.6x the work this kernel needs: the 9-tap "
-                               "patch sum is taken over pixel-level dot products, so 8d-flops / time exceeds the peak",
-            "frac_executed_mfma": tf(exec_flops) / FP32_MATRIX_PEAK_TFLOPS,
-            "frac_useful_flops": tf(useful) / FP32_MATRIX_PEAK_TFLOPS,
-            "frac_sec8d_algorithmic": tf(algo) / FP32_MATRIX_PEAK_TFLOPS,
+    return {"bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"corr_argmax_mfma_kernel<{C}>", "achieved": _tf(exec_flops, kms),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(exec_flops, kms) / FP32_MATRIX_PEAK_TFLOPS,
+            "frac_definition": "executed fp32 MFMA flops / peak (hardware utilisation, <= 1)",
+            "traffic": pmc.get("corr_hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
+            "kernel_ms": kms, "launches_timed": n,
+            "frac_useful_flops": _tf(useful, kms) / FP32_MATRIX_PEAK_TFLOPS,
             "executed_flops_per_launch": exec_flops, "useful_flops_per_launch": useful,
-            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": tf(algo),
+            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": _tf(algo, kms),
+            "algorithmic_note": "SURVEY 8d's figure is the reference's conv2d formulation, 8.6x the work this kernel needs (the "
+                                "9-tap patch sum is taken over pixel-level dot products): its rate exceeds the peak",
             "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None,
             "duplicate_row_elimination": "ref rows that repeat the three rows above them bit for bit (the zero-padding band "
-                                         "of a 500x500 Ref) are not swept: their patches tie with an earlier, lower-index "
-                                         "patch and can never be the reference's first maximum.  Exact; data-dependent "
-                                         "(no such rows -> full sweep)"}
+                                         "of a 500x500 Ref) are not swept: exact, data-dependent (no such rows -> full sweep)"}
 
 
-def dcn_roofline(name, B, C, Co, H, kms, n):
-    flops = B * 2.0 * Co * 9 * C * H * H                     # SURVEY.md 8d: 2*Co*(9C)*H*W per sample
-    tf = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-    return {"bound": "mfma", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": tf,
-            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
-            "kernel_ms": kms, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+def dcn_roofline(name, B, C, Co, H, kms, n, traffic=None, src=None):
+    flops = B * 2.0 * Co * 9 * C * H * H                     # SURVEY.md 8d: 2*Co*(9C)*H*W per sample (executed = algorithmic)
+    return {"bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": _tf(flops, kms),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(flops, kms) / FP32_MATRIX_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": src, "kernel_ms": kms, "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
-def conv_roofline(kms_total, flops_total, flops_exec, n, traffic=None):
-    """All conv3x3 launches of one step taken as one unit: algorithmic FLOPs = sum of 2*Cout*9*Cin*H*W*B (the formula
-    SURVEY.md 8d applies to the DCNv2 GEMMs), time = sum of the HIP-event kernel times, traffic = HBM bytes of those launches.
-    `achieved` / `frac` follow the spec (ALGORITHMIC flops / time): launches that run the Winograd F(2,3) kernel execute only
-    2/3 of their algorithmic flops on the matrix pipes, so `frac` can exceed the executed-MFMA utilisation given beside it."""
-    tf = flops_total / (kms_total * 1e-3) / 1e12 if kms_total > 0 else 0.0
-    tfe = flops_exec / (kms_total * 1e-3) / 1e12 if kms_total > 0 else 0.0
-    return {"bound": "mfma", "kernel": "conv3x3_kernel<MT, MODE> + conv3x3_wino_kernel (all fused channels-last 3x3 convolutions "
-                                       "of one step: decoder, offset heads, VGG19 taps, both extractor towers)",
-            "achieved": tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MATRIX_PEAK_TFLOPS,
-            "frac_executed_mfma": tfe / FP32_MATRIX_PEAK_TFLOPS, "executed_mfma_tflops": tfe,
-            "traffic": traffic, "kernel_ms": kms_total, "launches_timed": n, "algorithmic_flops_per_launch": flops_total,
-            "executed_flops_per_launch": flops_exec, "per": "step (sum over the step's launches)"}
+def _is_split_family(k):
+    return "split" in k or k == "bf16" or k.endswith("_bf16")
+
+
+def conv_rooflines(kern, fam, steps, pmc):
+    """The 3x3 convolutions of one step, split by the matrix pipe they run on.  fam = ops.conv_flops_by_family() of the
+    timed steps: {family: [launches, algorithmic flops, executed matrix flops]}."""
+    out = []
+    for kid, pipe, peak in (("conv3x3_split", "bf16 MFMA", BF16_MATRIX_PEAK_TFLOPS), ("conv3x3_mfma", "fp32 MFMA", FP32_MATRIX_PEAK_TFLOPS)):
+        ms = kern.get(kid, [])
+        if not ms:
+            continue
+        mine = {k: v for k, v in fam.items() if _is_split_family(k) == (kid == "conv3x3_split")}
+        algo = sum(v[1] for v in mine.values()) / steps
+        execd = sum(v[2] for v in mine.values()) / steps
+        kms = sum(ms) / steps
+        e = {"bound": "mfma", "pipe": pipe,
+             "kernel": ("conv3x3_split_kernel (csrc/conv3x3_split.hip: fp32-accurate 3x3 convolution on the bf16 matrix pipe -- three "
+                        "exact bf16 pieces per operand, six MFMAs per product sum; decoder, DCN heads, VGG19 taps, extractor towers)"
+                        if kid == "conv3x3_split" else
+                        "conv3x3_kernel / conv3x3_wino*_kernel / conv3x3_c3_kernel (csrc/conv3x3.hip, fp32 MFMA: first layers of "
+                        "the image towers and whatever $C2M_CONV_SPLIT keeps off the split kernel)"),
+             "achieved": _tf(execd, kms), "peak": peak, "unit": "TFLOP/s", "frac": _tf(execd, kms) / peak,
+             "frac_definition": "executed matrix flops / dense peak of that pipe (<= 1)",
+             "kernel_ms": kms, "launches_timed": len(ms), "per": "step (sum over the step's launches)",
+             "algorithmic_flops_per_launch": algo, "executed_flops_per_launch": execd,
+             "algorithmic_equiv_tflops": _tf(algo, kms),
+             "algorithmic_equiv_frac_of_fp32_mfma_peak": _tf(algo, kms) / FP32_MATRIX_PEAK_TFLOPS,
+             "families": {k: {"launches_per_step": v[0] / steps, "algorithmic_tflop_per_step": v[1] / steps / 1e12} for k, v in mine.items()},
+             "traffic": pmc.get(f"{kid}_hbm_bytes_per_step"), "traffic_source": pmc.get("source")}
+        if kid == "conv3x3_split":
+            e["frac_of_sustained_bf16_rate"] = _tf(execd, kms) / BF16_SUSTAINED_TFLOPS
+            e["sustained_note"] = ("back-to-back v_mfma_f32_32x32x16_bf16 on every SIMD with non-zero operands sustains "
+                                   f"{BF16_SUSTAINED_TFLOPS:.0f} TF on this chip (power: ~1.7 GHz), scripts/ubench/mfma_bf16_rate.hip")
+        out.append(e)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (outside the timed region, rank 0, N=1 only)
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_restore(ext, mp, net, lq, up, ref, threads=None, gpu_idx=None):
-    """ONE pair of the same batch through the same forward on the host cores (oracle/cpu_chain.py): stock torch-CPU
-    convolutions, the reference's conv2d-filter correlation algorithm (ref_map_util.py:26-86), oracle pre-offsets and
-    oracle DCNv2 (the reference has no CPU DCNv2).  ~10-20 s on the GPU box's cores."""
+def host_cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(phys) or max(1, logical // 2)), logical
+
+
+def cpu_baseline_restore(ext, mp, net, lq, up, ref, sr_gpu, idx_gpu, one_thread=True):
+    """The same forward on the host cores (oracle/cpu_chain.py: stock torch-CPU convolutions, the reference's conv2d-filter
+    correlation algorithm ref_map_util.py:26-86, oracle pre-offsets and oracle DCNv2 -- the reference has no CPU DCNv2).
+    Warm-up run + three timed runs (median), each on a different pair of the timed batch (first, middle, last) so that the
+    parity of the GPU forward is checked on three pairs: index map vs the CPU chain's own, SR vs the CPU chain run with ITS OWN
+    index map (unconditional) and, for pair 0, with the GPU's index map (isolates the decoder from near-tie flips)."""
+    import torch
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import cpu_chain
     import c2m_oracle
-    threads = threads or os.cpu_count()
+    model, phys, logical = host_cpu_info()
+    threads = phys
     torch.set_num_threads(threads)
     c2m_oracle.set_num_threads(min(threads, 64))
-    tm = {}
-    t0 = time.perf_counter()
-    sr, idx, feats = cpu_chain.full_forward_cpu(ext, mp, net, lq[:1], up[:1], ref[:1], True, tm, idx_for_offsets=gpu_idx)
-    dt = time.perf_counter() - t0
-    cpu_baseline_restore.margins = (cpu_chain.mismatch_margins(feats["dense_features1"][0], feats["dense_features2"][0],
-                                                                gpu_idx[0], idx[0]) if gpu_idx is not None else [])
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"1 of the {lq.shape[0]} pairs of one step, whole forward (extractor, correlation as conv2d filters + "
-                      f"running max, pre-offsets, VGG taps, RestorationNet with oracle DCNv2) on PyTorch-CPU + C oracle, "
-                      f"{dt:.1f}s", "stage_s": tm}, sr, idx
+    B = lq.shape[0]
+    pairs = sorted({0, B // 2, B - 1})
+
+    def run(b, idx_for_offsets=None):
+        tm = {}
+        t0 = time.perf_counter()
+        sr, idx, feats = cpu_chain.full_forward_cpu(ext, mp, net, lq[b:b + 1], up[b:b + 1], ref[b:b + 1], True, tm,
+                                                    idx_for_offsets=idx_for_offsets)
+        return time.perf_counter() - t0, tm, sr, idx, feats
+
+    # warm-up (page in, thread pools); doubles as the "given the GPU's index map" parity run of pair 0
+    _, _, sr_cond, _, _ = run(0, idx_for_offsets=idx_gpu[0:1])
+    times, stage, parity = [], [], []
+    for b in pairs:
+        dt, tm, sr_cpu, idx_cpu, feats = run(b)
+        times.append(dt)
+        stage.append(tm)
+        d = (sr_gpu[b].cpu() - sr_cpu[0]).abs()
+        mg = cpu_chain.mismatch_margins(feats["dense_features1"][0], feats["dense_features2"][0], idx_gpu[b], idx_cpu[0])
+        parity.append({"pair": b, "index_map_equal_fraction": float((idx_gpu[b] == idx_cpu[0]).mean()),
+                       "index_map_mismatches": len(mg), "of_queries": int(idx_gpu[b].size),
+                       "max_abs_fp64_score_margin_of_mismatches": max((abs(m[3]) for m in mg), default=0.0),
+                       "sr_max_abs_diff_unconditional": float(d.max()), "sr_pixels_over_1e-3": int((d > 1e-3).sum()),
+                       "sr_pixels": int(d.numel())})
+    med = sorted(times)[len(times) // 2]
+    out = {"value": 1.0 / med, "unit": "pairs/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+           "sample": f"{len(pairs)} of the {B} pairs of one step (pairs {pairs}), one at a time after a warm-up run, median of the "
+                     f"{len(times)} timings ({', '.join(f'{t:.1f}' for t in times)} s): whole forward (extractor, correlation as "
+                     "conv2d filters + running max, pre-offsets, VGG taps, RestorationNet with oracle DCNv2) on PyTorch-CPU + C oracle",
+           "stage_s_median_run": stage[times.index(med)],
+           "parity_gpu_vs_cpu": parity,
+           "parity_note": "index-map mismatches are fp32 near-ties of the extractor features (two convolution implementations, "
+                          "same weights; the float64 score margin of the two picks is given): the correlation kernel itself is "
+                          "bit-exact on identical features.  sr_*_unconditional: CPU chain with its OWN index map",
+           "sr_max_abs_diff_given_gpu_index_map_pair0": float((sr_gpu[0].cpu() - sr_cond[0]).abs().max())}
+    if one_thread:
+        out["one_thread"] = cpu_one_thread(ext, mp, net, lq, up, ref)
+    return out
 
 
-def cpu_baseline_corr(h, C, threads=None, budget_s=12.0):
+def cpu_one_thread(ext, mp, net, lq, up, ref):
+    """1-thread figure on bounded samples of the same pair (a whole configs[2] pair takes minutes on one core): extractor +
+    VGG taps on the full images, correlation on a slice of query rows (cost is linear in query rows), RestorationNet on the
+    top-left quarter of the LR image (convolution / DCNv2 cost is linear in pixels) -- each scaled to the full pair."""
+    import copy
+    import torch
+    import torch.nn.functional as F
+    import cpu_chain
+    import c2m_oracle
+    import torch_port
+    torch.set_num_threads(1)
+    c2m_oracle.set_num_threads(1)
+    ext_c, mp_c = copy.deepcopy(ext).cpu().eval(), copy.deepcopy(mp).cpu().eval()
+    g_c = cpu_chain.cpu_copy(net)
+    l1, u1, r1 = lq[:1].cpu(), up[:1].cpu(), ref[:1].cpu()
+    h = l1.shape[2]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats = ext_c(u1, r1)
+        ref_feat = mp_c.vgg(r1)
+        t_ext = time.perf_counter() - t0
+        f1 = F.normalize(feats["dense_features1"][0], dim=0)
+        f2 = F.normalize(feats["dense_features2"][0], dim=0)
+        rows = 6                                              # 4 query-patch rows of h-2
+        t0 = time.perf_counter()
+        torch_port.feature_match_index_conv(f1[:, :rows].contiguous(), f2, 3, 1, 1, True, True)
+        t_corr = (time.perf_counter() - t0) * (h - 2) / (rows - 2)
+        q = h // 4                                             # 1/16 of the pixels
+        idx = torch.zeros((q - 2, q - 2), dtype=torch.int64)
+        offs = c2m_oracle.build_pre_offsets(idx.numpy(), q, q)
+        pre = {"relu3_1": torch.from_numpy(offs[0])[None], "relu2_1": torch.from_numpy(offs[1])[None],
+               "relu1_1": torch.from_numpy(offs[2])[None]}
+        rf = {"relu3_1": ref_feat["relu3_1"][:, :, :q, :q].contiguous(), "relu2_1": ref_feat["relu2_1"][:, :, :2 * q, :2 * q].contiguous(),
+              "relu1_1": ref_feat["relu1_1"][:, :, :4 * q, :4 * q].contiguous()}
+        t0 = time.perf_counter()
+        g_c(l1[:, :, :q, :q].contiguous(), pre, rf)
+        t_rest = (time.perf_counter() - t0) * 16.0
+    total = t_ext + t_corr + t_rest
+    return {"value": 1.0 / total, "unit": "pairs/s", "cores": 1,
+            "sample": f"one pair, one thread: extractor + VGG taps measured in full ({t_ext:.1f} s), correlation on 4 of {h - 2} query "
+                      f"rows x {(h - 2) / 4:.1f} ({t_corr:.1f} s), RestorationNet on 1/16 of the pixels x 16 ({t_rest:.1f} s)"}
+
+
+def cpu_baseline_corr(h, C, budget_s=12.0):
     """configs[1] alone: reference algorithm on PyTorch-CPU, a bounded slice of query rows of one pair."""
+    import torch
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch_port
-    threads = threads or os.cpu_count()
-    torch.set_num_threads(threads)
+    model, phys, logical = host_cpu_info()
+    torch.set_num_threads(phys)
     g = torch.Generator().manual_seed(1234)
     fi_full = torch.nn.functional.normalize(torch.randn((C, h, h), generator=g), dim=0)
     fr = torch.nn.functional.normalize(torch.randn((C, h, h), generator=g), dim=0)
@@ -192,14 +338,15 @@ def cpu_baseline_corr(h, C, threads=None, budget_s=12.0):
 
     rows = min(48, h)
     dt = run(rows)
-    want = int(min(h, max(rows, 2 + (rows - 2) * budget_s / max(dt, 1e-3))))
-    if want > rows + 8:
-        rows = want
-        dt = run(rows)
+    want = int(min(h, max(rows, 2 + (rows - 2) * budget_s / 3 / max(dt, 1e-3))))
+    rows = max(rows, want)
+    ts = sorted(run(rows) for _ in range(3))
+    dt = ts[1]
     frac = (rows - 2) / (h - 2)
-    return {"value": frac / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{rows} of {h} query rows of one {h}x{h}x{C} pair vs full ref map, PyTorch-CPU conv2d+max "
-                      f"(reference algorithm, oracle/torch_port.py), {dt:.2f}s; linear extrapolation to a pair"}
+    return {"value": frac / dt, "unit": "pairs/s", "cores": phys, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "logical_cpus": logical,
+            "sample": f"{rows} of {h} query rows of one {h}x{h}x{C} pair vs full ref map, PyTorch-CPU conv2d+max (reference "
+                      f"algorithm, oracle/torch_port.py), median of 3 ({dt:.2f} s); linear extrapolation to a pair"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -208,28 +355,42 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU per step")
-    ap.add_argument("--lr", type=int, default=160, help="LR size = feature-map size")
-    ap.add_argument("--workload", choices=("restore", "corr"), default="restore")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default 16; 4 for --workload train and --lr 320)")
+    ap.add_argument("--lr", type=int, default=None, help="LR size = feature-map size (default 160; 40 for --workload train)")
+    ap.add_argument("--workload", choices=("restore", "corr", "train"), default="restore")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="bf16: inference under torch.autocast(bfloat16) (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("C2M_BENCH_FORCE_DIST") == "1":   # (the env var: exercise the RCCL path on a 1-GPU box)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for the barrier + max only
+        if not dist.is_initialized():
+            if "MASTER_ADDR" not in os.environ:
+                os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    rccl_world = dist.get_world_size() if dist is not None else None
 
     import c2m_amd
     ops = c2m_amd.ops
-    B, C, h = args.batch, 256, args.lr
+    train = args.workload == "train"
+    h = args.lr or (40 if train else 160)
+    B = args.batch or (4 if (train or h >= 320) else 16)
+    C = 256
 
     def sync():
         torch.cuda.synchronize()
@@ -250,26 +411,82 @@ def main():
                 out = step_fn()
         sync()
         dt = time.perf_counter() - t0
-        timed.conv_flops_exec = ops.conv_flops_of_last_steps(reset=False, executed=True)
-        timed.conv_flops = ops.conv_flops_of_last_steps()
+        timed.families = ops.conv_flops_by_family()
+        ops.count_conv_flops(False)
         prof = c2m_amd.profile_collect(capacity=65536)
         c2m_amd.profile_enable(False)
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, prof, out
+        kern = {}
+        for name, ms in prof:
+            kern.setdefault(name, []).append(ms)
+        return dt, kern, out
 
-    # HBM bytes from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
-    # very command; gfx950 corrections applied by the summariser) -- valid for the default workload only
-    traffic, pmc = None, {}
+    def finish(line):
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+
+    # HBM bytes from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this very
+    # command; gfx950 corrections applied by scripts/summarize_step.py).  STATIC: measured once per round on the default
+    # workload, not during this run -- `traffic_source` says so in the line
+    pmc = {}
     tfile = os.path.join(REPO, "profiles", "step_pmc_traffic.json")
-    if os.path.exists(tfile) and (B, h) == (16, 160):
+    if os.path.exists(tfile) and (B, h, args.workload, args.dtype) == (16, 160, "restore", "f32"):
         pmc = json.load(open(tfile))
-        traffic = pmc.get("corr_hbm_bytes_per_launch")
+        pmc["source"] = ("profiles/step_pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                         f"`python bench.py`, {pmc.get('measured_at', 'see profiles/README.md')}; not re-measured in this run)")
+    base = {"unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "data": "synthetic", "rccl_world_size": rccl_world}
 
-    # ---- configs[1] leg: correlation only on synthetic features (always run: sub-record of the default line) -------
-    valid = (500 * h) // 640  # 500x500 Ref inside the 640x640 padded canvas, at feature scale
+    # ---- configs[3]: stage-3 training step ---------------------------------------------------------------------------
+    if train:
+        import warnings
+        from mmsr.models.base_model import unwrap
+        from mmsr.models.ref_restoration_model import RefRestorationModel
+        opt = {"dist": dist is not None, "gpu_ids": [local_rank], "is_train": True, "path": {},
+               "network_g": {"type": "RestorationNet", "ngf": 64, "n_blocks": 16, "groups": 8},
+               "network_map": {"type": "CorrespondenceGenerationArch", "patch_size": 3, "stride": 1,
+                               "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
+               "network_extractor": {"type": "ContrasExtractorSep"},
+               "train": {"lr_g": 1e-4, "lr_offset": 1e-4, "lr_relu2_offset": 1e-5, "lr_relu3_offset": 1e-6,
+                         "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0}}
+        torch.manual_seed(10)     # same initial weights on every rank (DDP broadcasts rank 0's anyway)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            model = RefRestorationModel(opt)
+        g = torch.Generator().manual_seed(100 + rank)
+        gt = torch.rand((B, 3, 4 * h, 4 * h), generator=g)
+        lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+        up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+        model.feed_data({"img_in_lq": lq, "img_ref": torch.rand((B, 3, 4 * h, 4 * h), generator=g), "img_in": gt, "img_in_up": up})
+        it = [0]
+
+        def train_step():
+            it[0] += 1
+            model.optimize_parameters(it[0])
+            return model.log_dict["l_g_pix"]
+
+        dt, kern, loss = timed(train_step)
+        grad_bytes = sum(p.numel() * 4 for p in unwrap(model.net_g).parameters() if p.requires_grad)
+        line = dict(base, metric=METRIC + " -- stage-3 training step", value=B * world * args.steps / dt,
+                    ms_per_step=dt / args.steps * 1e3, dtype="f32",
+                    config={"workload": f"configs[3]: stage-3 MSE training step (extractor + correspondence under no_grad, RestorationNet "
+                                        f"forward, L1 loss, backward incl. three DCNv2 backward passes, Adam with the reference's four "
+                                        f"parameter groups), {B} pairs per GPU, GT {4*h}x{4*h} (LR {h}x{h}, Ref {4*h}x{4*h})",
+                            "global_batch": B * world,
+                            "parallelism": f"dp{world}" + (" (DDP over RCCL: one all-reduce of net_g's gradients per step, bucketed, "
+                                                          "overlapped with backward)" if dist is not None else " (single process)")},
+                    gradient_allreduce_bytes_per_step_per_gpu=grad_bytes if dist is not None else 0,
+                    net_g_gradient_bytes=grad_bytes, loss=float(loss),
+                    c2m_kernel_ms_per_step={k: sum(v) / args.steps for k, v in kern.items()})
+        return finish(line)
+
+    # ---- configs[1] leg: correlation only on synthetic features (sub-record of the default line) --------------------
+    valid = min(h, 125)   # 500x500 Ref inside the zero-padded canvas, at feature scale (/4)
     fin, fref = synth_features(B, C, h, valid, dev, 1234 + rank)
 
     def corr_step():
@@ -279,50 +496,45 @@ def main():
         return idx, val, ops.build_pre_offsets(idx, h, h)
 
     if args.workload == "corr":
-        dt, prof, out = timed(corr_step)
+        dt, kern, out = timed(corr_step)
         assert int(out[0].min()) >= 0 and int(out[0].max()) < (h - 2) ** 2
         swept = corr_swept_rows(h)
-        if rank == 0:
-            kern = [ms for (name, ms) in prof if name == "corr_argmax_mfma"]
-            kms = sum(kern) / max(len(kern), 1)
-            line = {"metric": METRIC + " -- correlation + index map only", "value": B * world * args.steps / dt,
-                    "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                    "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                    "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), feature "
-                                           "normalise + 3x3 correlation/arg-max index map + pre-offset maps (NO DCNv2 / decoder)",
-                               "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
-                    "roofline": corr_roofline(B, C, h, kms, len(kern), traffic, swept)}
-            if world == 1 and not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline_corr(h, C)
-            print(json.dumps(line))
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        ck = kern.get("corr_argmax_mfma", [])
+        line = dict(base, metric=METRIC + " -- correlation + index map only", value=B * world * args.steps / dt,
+                    ms_per_step=dt / args.steps * 1e3, dtype="f32",
+                    config={"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), feature "
+                                        "normalise + 3x3 correlation/arg-max index map + pre-offset maps (NO DCNv2 / decoder)",
+                            "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
+                    roofline=corr_roofline(B, C, h, sum(ck) / max(len(ck), 1), len(ck), pmc, swept))
+        if world == 1 and not args.no_cpu_baseline and rank == 0:
+            line["cpu_baseline"] = cpu_baseline_corr(h, C)
+        return finish(line)
 
-    # ---- configs[2]: full restoration forward ---------------------------------------------------------------------
+    # ---- configs[2] / configs[4]: full restoration forward -----------------------------------------------------------
     ext, mp, net = build_models(dev)
     lq, up, ref = synth_images(B, h, dev, 1234 + rank)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
     it = [0]
     last = {}
+    bf16 = args.dtype == "bf16"
 
     @torch.no_grad()
     def restore_step():
         e = ev[it[0]]
         it[0] += 1
-        e[0].record()
-        feats = ext(up, ref)
-        e[1].record()
-        pre, ref_feat = mp(feats, ref)
-        e[2].record()
-        sr = net(lq, pre, ref_feat)
-        e[3].record()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            e[0].record()
+            feats = ext(up, ref)
+            e[1].record()
+            pre, ref_feat = mp(feats, ref)
+            e[2].record()
+            sr = net(lq, pre, ref_feat)
+            e[3].record()
         last["pre"] = pre
         return sr
 
-    dt, prof, sr = timed(restore_step)
-    conv_flops, conv_flops_exec = timed.conv_flops, timed.conv_flops_exec
+    dt, kern, sr = timed(restore_step)
+    fam = timed.families
     swept = corr_swept_rows(h)   # of the timed steps' correlation launch (same inputs every step)
     assert tuple(sr.shape) == (B, 3, 4 * h, 4 * h) and bool(torch.isfinite(sr).all())
     stage = {"extractor": 0.0, "correspondence": 0.0, "restoration": 0.0}
@@ -330,74 +542,51 @@ def main():
         for k, name in enumerate(stage):
             stage[name] += e[k].elapsed_time(e[k + 1]) / args.steps
 
-    # configs[1] sub-record (short: 3 steps)
     sub = None
-    if rank == 0:
+    if rank == 0 and dist is None and h == 160 and not bf16:   # configs[1] sub-record (short: 3 steps)
         steps_keep, args.steps = args.steps, 3
-        sdt, sprof, _ = timed(corr_step) if dist is None else (None, None, None)
+        sdt, skern, _ = timed(corr_step)
         args.steps = steps_keep
-        if sdt is not None:
-            sk = [ms for (name, ms) in sprof if name == "corr_argmax_mfma"]
-            sub = {"workload": "configs[1]: normalise + correlation/arg-max + pre-offsets on synthetic features (round-1 headline)",
-                   "pairs_per_s": B * 3 / sdt, "ms_per_step": sdt / 3 * 1e3, "corr_kernel_ms": sum(sk) / max(len(sk), 1)}
+        sk = skern.get("corr_argmax_mfma", [])
+        sub = {"workload": "configs[1]: normalise + correlation/arg-max + pre-offsets on synthetic features (round-1 headline)",
+               "pairs_per_s": B * 3 / sdt, "ms_per_step": sdt / 3 * 1e3, "corr_kernel_ms": sum(sk) / max(len(sk), 1)}
 
+    line = None
     if rank == 0:
-        kern = {}
-        for name, ms in prof:
-            kern.setdefault(name, []).append(ms)
         rl = []
         ck = kern.get("corr_argmax_mfma", [])
         if ck:
-            rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), traffic, swept))
+            rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), pmc, swept))
         dk = kern.get("dcn_v2_forward", [])
         layers = (("small", 256, h), ("medium", 128, 2 * h), ("large", 64, 4 * h))
         if dk and len(dk) % 3 == 0:   # launch order inside a step: small, medium, large (ref_restoration_arch.py:152-180)
             dtraf = sorted(pmc.get("dcn_v2_forward_hbm_bytes_per_launch", {}).values())   # small < medium < large
             for k, (lname, ch, hh) in enumerate(layers):
                 mine = dk[k::3]
-                rl.append(dcn_roofline(lname, B, ch, ch, hh, sum(mine) / len(mine), len(mine)))
-                if len(dtraf) == 3:
-                    rl[-1]["traffic"] = dtraf[k]
+                rl.append(dcn_roofline(lname, B, ch, ch, hh, sum(mine) / len(mine), len(mine),
+                                       dtraf[k] if len(dtraf) == 3 else None, pmc.get("source")))
             tot = sum(dk) / (len(dk) // 3)
             flops = sum(B * 2.0 * ch * 9 * ch * hh * hh for _, ch, hh in layers)
-            rl.append({"bound": "mfma", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
-                       "achieved": flops / (tot * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": flops / (tot * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel_ms": tot,
+            rl.append({"bound": "mfma", "pipe": "fp32 MFMA", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
+                       "achieved": _tf(flops, tot), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": _tf(flops, tot) / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel_ms": tot,
                        "launches_timed": len(dk), "algorithmic_flops_per_launch": flops,
                        "north_star_target": ">= 0.50 MFMA utilisation on DCNv2 forward at batch 16"})
-        cv = kern.get("conv3x3_mfma", [])
-        if cv:
-            rl.append(conv_roofline(sum(cv) / args.steps, conv_flops / args.steps, conv_flops_exec / args.steps, len(cv),
-                                    pmc.get("conv3x3_hbm_bytes_per_step")))
-        dominant = max(rl, key=lambda r: r["kernel_ms"]) if rl else None
-        line = {
-            "metric": METRIC, "value": B * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: batch-{B} full restoration forward (extractor + correlation/index map + "
-                                   f"pre-offsets + VGG taps + RestorationNet with 3 DCNv2 warps + decoder), LR {h}x{h}, Ref "
-                                   f"500x500 zero-padded to {4*h}x{4*h}, SR {4*h}x{4*h}, fp32, {B} pairs per GPU per step",
-                       "parallelism": f"dp{world} (batch-sharded, no collective)"},
-            "stage_ms": stage, "roofline": dominant, "roofline_kernels": rl, "configs1_corr_only": sub,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            gpu_idx = last["pre"].max_idx[:1].cpu().numpy()
-            base, sr_cpu, idx_cpu = cpu_baseline_restore(ext, mp, net, lq, up, ref, gpu_idx=gpu_idx)
-            # parity of the timed GPU forward against the CPU chain on pair 0: index map (the CPU map comes from oneDNN
-            # convolutions of the extractor, so fp32 near-ties may flip) and SR pixels given the same index map
-            base["index_map_equal_fraction_gpu_vs_cpu_pair0"] = float((gpu_idx == idx_cpu).mean())
-            mg = cpu_baseline_restore.margins
-            base["index_map_mismatches_pair0"] = {
-                "queries": len(mg), "of": int(gpu_idx[0].size),
-                "max_abs_fp64_score_margin": max((abs(m[3]) for m in mg), default=0.0),
-                "note": "queries where the GPU and the CPU chain pick different ref patches, and the float64 score difference of "
-                        "the two picks on the CPU features: fp32 near-ties of the extractor features (two convolution "
-                        "implementations, same weights); the correlation kernel itself is bit-exact on identical features"}
-            base["sr_max_abs_diff_gpu_vs_cpu_pair0"] = float((sr[0].cpu() - sr_cpu[0]).abs().max())
-            line["cpu_baseline"] = base
-        print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+        rl += conv_rooflines(kern, fam, args.steps, pmc)
+        dominant = max((r for r in rl if "all three" not in r["kernel"]), key=lambda r: r["kernel_ms"]) if rl else None
+        cfg = (f"configs[4]: CUFED5-shape inference, LR {h}x{h} / Ref 500x500 zero-padded to {4*h}x{4*h}, bf16 autocast (convolutions: "
+               f"one bf16 piece per operand, fp32 accumulation; matching and DCNv2 in fp32), {B} pairs per GPU per step" if bf16 else
+               f"configs[2]: batch-{B} full restoration forward (extractor + correlation/index map + pre-offsets + VGG taps + "
+               f"RestorationNet with 3 DCNv2 warps + decoder), LR {h}x{h}, Ref 500x500 zero-padded to {4*h}x{4*h}, SR {4*h}x{4*h}, "
+               f"fp32, {B} pairs per GPU per step")
+        line = dict(base, metric=METRIC, value=B * world * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
+                    dtype="bf16" if bf16 else "f32",
+                    config={"workload": cfg, "parallelism": f"dp{world} (batch-sharded, no collective)"},
+                    stage_ms=stage, roofline=dominant, roofline_kernels=rl, configs1_corr_only=sub)
+        if world == 1 and not args.no_cpu_baseline and not bf16:
+            idx_gpu = last["pre"].max_idx.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline_restore(ext, mp, net, lq, up, ref, sr, idx_gpu)
+    finish(line)
 
 
 if __name__ == "__main__":

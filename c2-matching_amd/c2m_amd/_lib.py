@@ -79,6 +79,10 @@ def _declare(L):
     L.c2m_conv3x3_relayout_split_bytes.restype = _sz
     L.c2m_conv3x3_relayout_split_bytes.argtypes = [_i, _i, _i]
     L.c2m_conv3x3_relayout_split_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
+    L.c2m_conv3x3_relayout_split_dgrad_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
+    L.c2m_conv3x3_wgrad_workspace_bytes.restype = _sz
+    L.c2m_conv3x3_wgrad_workspace_bytes.argtypes = [_i] * 5
+    L.c2m_conv3x3_wgrad_f32.argtypes = [_vp, ctypes.POINTER(ConvSrc), _i, _vp, _i, _i, ctypes.c_longlong] + [_i] * 5 + [_vp, _vp, _sz]
     L.c2m_conv3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(Conv3x3Desc)]
     L.c2m_index_to_flow_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
 
@@ -113,7 +117,7 @@ def device_arch():
 
 
 KERNEL_NAMES = {1: "corr_argmax_mfma", 2: "corr_argmax_generic", 3: "dcn_v2_forward", 4: "dcn_v2_backward_data",
-                5: "dcn_v2_backward_weight", 6: "conv3x3_mfma"}
+                5: "dcn_v2_backward_weight", 6: "conv3x3_mfma", 7: "conv3x3_split", 8: "conv3x3_wgrad"}
 
 
 def profile_enable(on=True):

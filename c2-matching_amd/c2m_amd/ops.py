@@ -316,9 +316,9 @@ class _WeightCache:
         w = w.contiguous()
         L = _lib.lib()
         wino = int(wino)
-        if wino in (3, 4):   # split-bf16 images (3 exact pieces / 1 rounded piece per weight)
-            pieces = 3 if wino == 3 else 1
-            nbytes = L.c2m_conv3x3_relayout_split_bytes(Ci, Co, pieces)
+        if wino in (3, 4, 5):   # split-bf16 images (3 exact pieces / 1 rounded piece per weight); 5: of the data-gradient conv
+            pieces = 1 if wino == 4 else 3
+            nbytes = L.c2m_conv3x3_relayout_split_bytes(Co, Ci, pieces) if wino == 5 else L.c2m_conv3x3_relayout_split_bytes(Ci, Co, pieces)
         else:
             nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
         if nbytes == 0:
@@ -327,7 +327,10 @@ class _WeightCache:
         if wr is None:
             wr = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            if wino in (3, 4):
+            if wino == 5:
+                _lib.check(L.c2m_conv3x3_relayout_split_dgrad_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
+                           "c2m_conv3x3_relayout_split_dgrad_f32")
+            elif wino in (3, 4):
                 _lib.check(L.c2m_conv3x3_relayout_split_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
                            "c2m_conv3x3_relayout_split_f32")
             else:
@@ -390,6 +393,13 @@ def _wino4_ok(srcs, weight, out_mode, W):
     return _WINO4 and W % 64 == 0 and out_mode == "nhwc" and _wino_ok(srcs, weight, out_mode, W)
 
 
+def bf16_autocast():
+    """True inside `torch.autocast('cuda', dtype=torch.bfloat16)`: the caller asked for reduced precision (BASELINE
+    configs[4]) -- the convolutions then run the split kernel with ONE round-to-nearest bf16 piece per operand (algo
+    "bf16": bf16 products, fp32 accumulation, fp32 tensors in and out), 1/6 of the matrix work of the fp32 flavour."""
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
 def _split_ok(srcs, weight, fast):
     """Split-bf16 kernel: any map size / output mode; 16-channel chunks; sources add up to the weight's input channels."""
     return ((_SPLIT == "all" or (fast and _SPLIT != "0")) and all(s.shape[1] % 16 == 0 for s in srcs) and
@@ -418,9 +428,10 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     Cout = weight.shape[0]
     dev = srcs[0].device
     if algo is None:
-        if (out2_grouped8 is None and _split_ok(srcs, weight, fast) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
+        reduced = bf16_autocast()
+        if (out2_grouped8 is None and (_split_ok(srcs, weight, fast) or (reduced and _split_ok(srcs, weight, True))) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
                 and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
-            wino = 3
+            wino = 4 if reduced else 3
         else:
             wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
@@ -479,6 +490,119 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     if _ConvFlops.enabled:
         _ConvFlops.add(_FAMILY[wino], 2.0 * Cout * 9 * Cin * H * W * B, 2.0 * Cout * 9 * Cin * H * W * B * _EXEC_FACTOR[wino])
     return out
+
+
+def conv3x3_dgrad(grad_out, weight):
+    """Data gradient of conv3x3: grad_out channels-last [B,Cout,H,W], weight [Cout,Cin,3,3] -> dX channels-last [B,Cin,H,W]
+    = conv3x3(grad_out, W') with W'[ci][co][dy][dx] = W[co][ci][2-dy][2-dx], on the split-bf16 kernel (fp32-accurate)."""
+    Cout, Cin = weight.shape[:2]
+    B, Cg, H, W = grad_out.shape
+    if Cg != Cout or Cout % 16 != 0 or Cin % 4 != 0:
+        raise _lib.C2MError("conv3x3_dgrad: grad_out channels must equal weight.shape[0] (a multiple of 16); Cin % 4 == 0")
+    wr = _wcache.get(weight, wino=5)
+    out = empty_nhwc(B, Cin, H, W, grad_out.device)
+    d = _lib.Conv3x3Desc()
+    d.algo = 3
+    d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cout, Cin, 1
+    d.src[0] = _nhwc_src(grad_out, "grad_out")
+    d.wr = wr.data_ptr()
+    d.out_mode = 0
+    o = _nhwc_src(out, "out")
+    d.out, d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = out.data_ptr(), o.pix_pitch, o.row_pitch, o.img_pitch
+    with torch.cuda.device(grad_out.device):
+        _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32 (dgrad)")
+    if _ConvFlops.enabled:
+        f = 2.0 * Cout * 9 * Cin * H * W * B
+        _ConvFlops.add("dgrad_split_bf16x3", f, f * 6.0)
+    return out
+
+
+def conv3x3_wgrad(srcs, grad_out, Cout):
+    """Weight gradient of conv3x3(cat(srcs)): srcs / grad_out channels-last -> grad_weight [Cout, Cin, 3, 3] (fp32 MFMA over
+    pixel segments, deterministic two-stage reduction; csrc/conv3x3_wgrad.hip)."""
+    srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
+    B, _, H, W = srcs[0].shape
+    Cin = sum(s_.shape[1] for s_ in srcs)
+    if tuple(grad_out.shape) != (B, Cout, H, W):
+        raise _lib.C2MError("conv3x3_wgrad: grad_out must be [B, Cout, H, W]")
+    dev = grad_out.device
+    L = _lib.lib()
+    arr = (_lib.ConvSrc * 2)()
+    for k, s_ in enumerate(srcs):
+        arr[k] = _nhwc_src(s_, f"src{k}")
+    g = _nhwc_src(grad_out, "grad_out")
+    gw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = L.c2m_conv3x3_wgrad_workspace_bytes(B, H, W, Cin, Cout)
+        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dev)
+        _lib.check(L.c2m_conv3x3_wgrad_f32(_stream(), arr, len(srcs), grad_out.data_ptr(), g.pix_pitch, g.row_pitch, g.img_pitch,
+                                           B, H, W, Cin, Cout, gw.data_ptr(), ws.data_ptr(), nbytes), "c2m_conv3x3_wgrad_f32")
+    return gw
+
+
+def _as_nhwc(t):
+    """float32 channels-last view / copy of a [B,C,H,W] tensor (what the kernels' pitch descriptors need)."""
+    t = t.float() if t.dtype != torch.float32 else t
+    return t if t.stride(1) == 1 else t.contiguous(memory_format=torch.channels_last)
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """Differentiable act(conv3x3(cat(srcs)) + bias) on the hand-written kernels: forward = the split-bf16 kernel, backward =
+    the same kernel on rotated / transposed weights (data gradient) + the fp32-MFMA weight-gradient kernel + two elementwise
+    torch ops (activation mask, bias sum).  Stage-3 training (ref_restoration_model.py:192-269) runs its decoder through this
+    instead of cuDNN/MIOpen convolutions."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, act, slope, *srcs):
+        srcs = [_as_nhwc(s_) for s_ in srcs]
+        out = conv3x3(srcs, weight, bias, act=act, slope=slope, algo="split")
+        ctx.act, ctx.slope, ctx.nsrc = int(act), float(slope), len(srcs)
+        ctx.save_for_backward(weight, *(srcs + ([out] if act != ACT_NONE else [])))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        weight, srcs = saved[0], list(saved[1:1 + ctx.nsrc])
+        g = _as_nhwc(grad_out)
+        if ctx.act != ACT_NONE:
+            out = saved[1 + ctx.nsrc]
+            g = g * torch.where(out > 0, 1.0, ctx.slope if ctx.act == ACT_LRELU else 0.0)
+            g = _as_nhwc(g)
+        need = ctx.needs_input_grad
+        gw = conv3x3_wgrad(srcs, g, weight.shape[0]) if need[0] else None
+        gb = g.sum(dim=(0, 2, 3)) if need[1] else None
+        gsrc = [None] * ctx.nsrc
+        if any(need[4:4 + ctx.nsrc]):
+            Co = weight.shape[0]
+            if Co % 16 != 0:   # the data-gradient convolution sweeps dY in 16-channel chunks: zero-pad (216-channel DCN heads)
+                pad = 16 - Co % 16
+                dx = conv3x3_dgrad(_as_nhwc(torch.nn.functional.pad(g, (0, 0, 0, 0, 0, pad))),
+                                   torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, pad)))
+            else:
+                dx = conv3x3_dgrad(g, weight)
+            c0 = 0
+            for k, s_ in enumerate(srcs):
+                if need[4 + k]:
+                    gsrc[k] = dx[:, c0:c0 + s_.shape[1]]
+                c0 += s_.shape[1]
+        return (gw, gb, None, None, *gsrc)
+
+
+def conv3x3_autograd(srcs, weight, bias=None, act=ACT_NONE, slope=0.1):
+    """act(conv3x3(cat(srcs)) + bias) with gradients (channels-last float32 in and out; sources a multiple of 32 channels,
+    Cout a multiple of 16).  See _Conv3x3Fn."""
+    srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
+    return _Conv3x3Fn.apply(weight, bias, int(act), float(slope), *srcs)
+
+
+def conv3x3_autograd_ok(srcs, weight):
+    """Shapes the differentiable path supports: 32-channel source blocks (weight-gradient kernel) and 16-byte channels-last
+    output vectors (Cout % 4 == 0; the data-gradient convolution pads Cout to a multiple of 16 itself)."""
+    srcs = list(srcs) if isinstance(srcs, (list, tuple)) else [srcs]
+    return (all(s_.is_cuda and s_.dim() == 4 and s_.shape[1] % 32 == 0 for s_ in srcs) and weight.shape[0] % 4 == 0 and
+            sum(s_.shape[1] for s_ in srcs) == weight.shape[1] and tuple(weight.shape[2:]) == (3, 3) and _SPLIT != "0")
 
 
 def _grouped8_args(g2, B, Cout, H, W, dev):
@@ -562,12 +686,13 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
     split = (Cout // 64) * 64
     slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
-    use_split = algo == "split" or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
+    use_split = algo in ("split", "bf16") or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
+    split_id = 4 if (algo == "bf16" or (algo is None and bf16_autocast())) else 3
     fam = []
     for (c0, c1) in slices:
         # split-bf16 kernel (any shape); else 64-channel-tileable slices on whole 32-pixel tiles take the Winograd F(2,3)
         # kernel (1.5x fewer matrix instructions), the rest the direct kernel
-        wino = 3 if use_split else int(_WINO and algo is None and (c1 - c0) % 64 == 0 and W % 32 == 0 and
+        wino = split_id if use_split else int(_WINO and algo is None and (c1 - c0) % 64 == 0 and W % 32 == 0 and
                                        all(s_.shape[1] % 16 == 0 for s_ in srcs))
         fam.append(wino)
         wr = _wcache.get(weight, rows=(c0, c1), wino=wino)

@@ -1392,7 +1392,7 @@ using namespace c2m;
 namespace c2m {
 namespace conv {   // conv3x3_split.hip
 size_t split_relayout_bytes(int Cin, int Cout, int np);
-int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr);
+int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad);
 int launch_split(hipStream_t st, Params p, int np);
 }  // namespace conv
 }  // namespace c2m
@@ -1401,7 +1401,13 @@ extern "C" size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces
 
 extern "C" int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr) {
   if (!weight || !wr) return C2M_ERR_INVALID_ARG;
-  return conv::split_relayout(as_stream(stream), weight, Cin, Cout, pieces, wr);
+  return conv::split_relayout(as_stream(stream), weight, Cin, Cout, pieces, wr, 0);
+}
+
+extern "C" int c2m_conv3x3_relayout_split_dgrad_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr) {
+  if (!weight || !wr) return C2M_ERR_INVALID_ARG;
+  // the data-gradient convolution maps Cout channels (of dY) to Cin channels (of dX)
+  return conv::split_relayout(as_stream(stream), weight, Cout, Cin, pieces, wr, 1);
 }
 
 namespace {
@@ -1565,7 +1571,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
   }
   if (splitk) {
-    ProfileScope prof(C2M_KERNEL_CONV3X3, as_stream(stream));
+    ProfileScope prof(C2M_KERNEL_CONV3X3_SPLIT, as_stream(stream));
     return conv::launch_split(as_stream(stream), p, d->algo == C2M_CONV_BF16 ? 1 : 3);
   }
   // tiles per workgroup: long streams amortise the set-up and the first DMA wait, but the launch is only as fast as its

@@ -96,8 +96,10 @@ __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) 
 
 // weights W[Cout][Cin][3][3] -> images [cb][chunk][dy][dx][plane NP][mt MT][k half 2][row 32][e 8] (bf16),
 // value = piece `plane` of W[cb*32*MT + mt*32 + row][chunk*16 + 8*half + e][dy][dx] (0 beyond Cout)
+// dgrad != 0: images of the DATA-GRADIENT convolution instead (Cin/Cout = its input/output channels = the forward's
+// Cout/Cin): value = piece of w[ci][co][2-dy][2-dx] with w the forward weight [Cin here][Cout here][3][3]
 __global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float* __restrict__ w, int Cin, int Cout, int NP, int MT,
-                                                                      long long total, unsigned short* __restrict__ wr) {
+                                                                      long long total, unsigned short* __restrict__ wr, int dgrad) {
   const long long e0 = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e0 >= total) return;
   const int e = (int)(e0 & 7), row = (int)((e0 >> 3) & 31), half = (int)((e0 >> 8) & 1);
@@ -110,7 +112,8 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float
   const int chunk = (int)(r % nch);
   const int cb = (int)(r / nch);
   const int co = (cb * MT + mt) * 32 + row, ci = chunk * KC + 8 * half + e;
-  const float v = co < Cout ? w[((size_t)co * Cin + ci) * 9 + dy * 3 + dx] : 0.0f;
+  float v = 0.0f;
+  if (co < Cout) v = dgrad ? w[((size_t)ci * Cout + co) * 9 + (2 - dy) * 3 + (2 - dx)] : w[((size_t)co * Cin + ci) * 9 + dy * 3 + dx];
   wr[e0] = bf16_piece(v, pl, NP == 1);
 }
 
@@ -553,12 +556,12 @@ size_t split_relayout_bytes(int Cin, int Cout, int np) {
   return (size_t)ncb * (Cin / split::KC) * 9 * np * MT * 1024;
 }
 
-int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr) {
+int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad) {
   const size_t bytes = split_relayout_bytes(Cin, Cout, np);
   if (bytes == 0) return C2M_ERR_UNSUPPORTED;
   const long long total = (long long)(bytes / 2);
   hipLaunchKernelGGL(split::conv3x3_relayout_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, Cin,
-                     Cout, np, Cout <= 32 ? 1 : 2, total, reinterpret_cast<unsigned short*>(wr));
+                     Cout, np, Cout <= 32 ? 1 : 2, total, reinterpret_cast<unsigned short*>(wr), dgrad);
   return check_launch();
 }
 

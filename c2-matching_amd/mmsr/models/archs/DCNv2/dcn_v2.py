@@ -197,12 +197,21 @@ class _SelfOffsetDCN(DCNv2):
         self.init_offset()
         self._watch = _OffsetMeanWatch()
 
+    #: False: the offset/mask head always runs as the stock nn.Conv2d (RestorationNet.allow_fused = False sets it)
+    allow_conv_kernels = True
+
     def init_offset(self):
         self.conv_offset_mask.weight.data.zero_()
         self.conv_offset_mask.bias.data.zero_()
 
     def _offset_and_mask(self, feat, pre_offset=None, watch=False):
-        raw = self.conv_offset_mask(feat)
+        head = self.conv_offset_mask
+        if (self.allow_conv_kernels and torch.is_grad_enabled() and feat.is_cuda and feat.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+                head.kernel_size == (3, 3) and head.stride == (1, 1) and head.padding == (1, 1) and
+                not head._forward_hooks and not head._forward_pre_hooks and _ops.conv3x3_autograd_ok([feat], head.weight)):
+            raw = _ops.conv3x3_autograd([feat], head.weight, head.bias)   # hand-written forward / backward kernels (training)
+        else:
+            raw = head(feat)
         abs_sum = None
         if watch:
             self._watch.poll()

@@ -15,11 +15,11 @@ class ContrasExtractorLayer(nn.Module):
         self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, batch):
+        from c2m_amd import ops as _ops
         if (not torch.is_grad_enabled() and batch.is_cuda and batch.dtype == torch.float32 and batch.shape[1] == 3 and
-                not torch.is_autocast_enabled('cuda')):
+                (not torch.is_autocast_enabled('cuda') or _ops.bf16_autocast())):
             # inference: the five convolutions (+ ReLU) on the fused channels-last kernel; conv3_1 (no ReLU,
             # contras_extractor_arch.py:21-23) is written planar for the correlation kernels
-            from c2m_amd import ops as _ops
             out = _ops.vgg_stack_forward(self.model._modules, batch, mean=self.mean, std=self.std, last_nchw=True)
             return out['conv3_1']
         return self.model((batch - self.mean) / self.std)

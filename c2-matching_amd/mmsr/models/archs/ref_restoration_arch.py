@@ -4,8 +4,11 @@ on the gfx950 DCNv2 kernels.
 
 Two execution paths over the SAME modules / parameters:
 
-* autograd (training, or any call with gradients enabled): module by module as the reference composes them, the plain
-  3x3 convolutions on stock torch (MIOpen), DynAgg through ``_DCNv2`` with the hand-written forward/backward kernels;
+* autograd (training, or any call with gradients enabled): the reference's composition with every 3x3 convolution that has
+  at least 32 input channels on the hand-written kernels FORWARD AND BACKWARD (``ops.conv3x3_autograd``: split-bf16 forward,
+  the same kernel on rotated / transposed weights for the data gradient, an fp32-MFMA weight-gradient kernel), DynAgg through
+  ``_DCNv2`` with the hand-written forward/backward kernels; ``allow_fused = False`` (or hooks on inner modules) falls back to
+  the stock modules (MIOpen);
 * fused inference (``torch.no_grad()``, fp32 on the GPU, ``pre_offset`` produced by this package's
   ``CorrespondenceGenerationArch``): the whole net runs channels-last on the hand-written gfx950 kernels --
   csrc/conv3x3.hip computes act(conv(cat(a, b)) + bias) + residuals in one launch per convolution (no cat / bias /
@@ -35,6 +38,12 @@ class ContentExtractor(nn.Module):
     def forward(self, x):
         return self.body(self.lrelu(self.conv_first(x)))
 
+    def forward_train(self, x):
+        """With gradients: conv_first (3 input channels) on the stock module, the 16 residual blocks on the hand-written
+        kernels (channels-last)."""
+        f = self.lrelu(self.conv_first(x)).contiguous(memory_format=torch.channels_last)
+        return _train_body(self.body, f)
+
     def forward_fused(self, x):
         """x [B,3,h,w] (any layout) -> content feature, channels-last.  A 3 -> 64 conv_first runs on the first-layer
         kernel; any other width sees the image zero-padded to 32 channels (the generic kernel's chunk size; the weights
@@ -55,6 +64,24 @@ def _has_hooks(module):
 
 def _fusable_body(body):
     return all(isinstance(b, arch_util.ResidualBlockNoBN) and b.res_scale == 1 for b in body)
+
+
+def _conv_t(m, srcs, act=_ops.ACT_NONE, slope=0.1):
+    """act(m(cat(srcs))) WITH gradients: the hand-written forward / data-gradient / weight-gradient kernels
+    (ops.conv3x3_autograd) where the shapes allow, the stock module otherwise (3-channel first / last convolutions)."""
+    if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and \
+            _ops.conv3x3_autograd_ok(srcs, m.weight):
+        return _ops.conv3x3_autograd(srcs, m.weight, m.bias, act, slope)
+    y = m(torch.cat(list(srcs), 1) if len(srcs) > 1 else srcs[0])
+    return F.relu(y) if act == _ops.ACT_RELU else F.leaky_relu(y, slope) if act == _ops.ACT_LRELU else y
+
+
+def _train_body(body, f, skip=None):
+    """16 x (x + conv2(relu(conv1(x)))) under autograd on the hand-written kernels (arch_util.py:128-136)."""
+    for blk in body:
+        t = _conv_t(blk.conv1, [f], _ops.ACT_RELU)
+        f = _conv_t(blk.conv2, [t]) + f
+    return f if skip is None else f + skip
 
 
 def _fused_body(body, f, skip=None):
@@ -106,6 +133,26 @@ class DynamicAggregationRestoration(nn.Module):
     def forward(self, x, pre_offset, img_ref_feat):
         for name, key, _ in self._STAGES:
             x = self._stage(name, x, img_ref_feat[key], pre_offset[key])
+        return x
+
+    def _stage_train(self, name, x, ref_feat, pre_offset):
+        """_stage() with every 3x3 convolution on the differentiable hand-written kernels (channels-last activations); the
+        DynAgg module keeps the reference's interface (NCHW tensors through _DCNv2), its offset/mask head included."""
+        lre = _ops.ACT_LRELU
+        ref_cl = _ops._as_nhwc(ref_feat)
+        of = _conv_t(getattr(self, f'{name}_offset_conv1'), [x, ref_cl], lre)
+        of = _conv_t(getattr(self, f'{name}_offset_conv2'), [of], lre)
+        swapped = self.lrelu(getattr(self, f'{name}_dyn_agg')([ref_feat, of], pre_offset))
+        h = _conv_t(getattr(self, f'head_{name}')[0], [x, _ops._as_nhwc(swapped)], lre)
+        h = _train_body(getattr(self, f'body_{name}'), h, skip=x)
+        tail = getattr(self, f'tail_{name}')
+        if name == 'large':
+            return tail[2](_conv_t(tail[0], [h], lre))          # 32 -> 3: stock module
+        return tail[2](tail[1](_conv_t(tail[0], [h])))          # conv -> PixelShuffle(2) -> lrelu
+
+    def forward_train(self, x, pre_offset, img_ref_feat):
+        for name, key, _ in self._STAGES:
+            x = self._stage_train(name, x, img_ref_feat[key], pre_offset[key])
         return x
 
     def _stage_fused(self, name, x, ref_feat, flow, scale):
@@ -167,8 +214,9 @@ class RestorationNet(nn.Module):
             return False
         if torch.is_grad_enabled() or not isinstance(pre_offset, PreOffsets) or not x.is_cuda or x.dtype != torch.float32:
             return False
-        if torch.is_autocast_enabled('cuda'):   # reduced-precision inference (BASELINE configs[4]) keeps the bf16 convs
-            return False
+        if torch.is_autocast_enabled('cuda') and not _ops.bf16_autocast():
+            return False   # (fp16 autocast: stock modules.  bf16 autocast -- BASELINE configs[4] -- stays on the fused path:
+                           # its convolutions then run the single-piece bf16 flavour of the split kernel, ops.conv3x3)
         ok_feats = all(img_ref_feat[k].dtype == torch.float32 and img_ref_feat[k].shape[1] == c
                        for _, k, c in DynamicAggregationRestoration._STAGES)
         if not (ok_feats and _fusable_body(self.content_extractor.body) and self.dyn_agg_restore.fusable()):
@@ -182,6 +230,18 @@ class RestorationNet(nn.Module):
         dg = self.dyn_agg_restore.large_dyn_agg.deformable_groups
         return 27 * dg * (4 * h) * (4 * w) * 4 < 2 ** 31 - 1
 
+    def _use_train_kernels(self, x, img_ref_feat):
+        """Gradients enabled (stage-3 training): the decoder's 3x3 convolutions run forward AND backward on the hand-written
+        kernels (ops.conv3x3_autograd) for fp32 GPU inputs outside autocast; `allow_fused = False` or forward hooks on inner
+        modules keep the stock module-by-module path."""
+        if not (self.allow_fused and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+            return False
+        if torch.is_autocast_enabled('cuda') or self.dyn_agg_restore.has_inner_hooks() or _has_hooks(self.content_extractor):
+            return False
+        return all(img_ref_feat[k].dtype == torch.float32 and img_ref_feat[k].shape[1] == c
+                   for _, k, c in DynamicAggregationRestoration._STAGES) and \
+            _fusable_body(self.content_extractor.body) and self.dyn_agg_restore.fusable()
+
     def forward(self, x, pre_offset, img_ref_feat):
         """x: LR image [B,3,h,w]; pre_offset / img_ref_feat: dicts keyed relu3_1 / relu2_1 / relu1_1."""
         base = F.interpolate(x, None, 4, 'bilinear', False)
@@ -189,5 +249,11 @@ class RestorationNet(nn.Module):
             _ops.refresh_weight_caches(self)   # cached weight images follow writes through .data (no version bump)
             content_feat = self.content_extractor.forward_fused(x)
             return self.dyn_agg_restore.forward_fused(content_feat, pre_offset.flow, img_ref_feat) + base
+        train_kernels = self._use_train_kernels(x, img_ref_feat)
+        for name, _, _ in DynamicAggregationRestoration._STAGES:   # the DynAgg heads follow this net's choice
+            getattr(self.dyn_agg_restore, f'{name}_dyn_agg').allow_conv_kernels = train_kernels
+        if train_kernels:
+            content_feat = self.content_extractor.forward_train(x)
+            return self.dyn_agg_restore.forward_train(content_feat, pre_offset, img_ref_feat) + base
         content_feat = self.content_extractor(x)
         return self.dyn_agg_restore(content_feat, pre_offset, img_ref_feat) + base

@@ -84,6 +84,11 @@ def build_vgg_features(vgg_type, upto, pretrained=True):
     return out
 
 
+def _bf16_autocast():
+    from c2m_amd import ops as _ops
+    return _ops.bf16_autocast()
+
+
 class VGGFeatureExtractor(nn.Module):
     """Returns {layer_name: feature} for the requested taps (vgg_arch.py:59-145)."""
 
@@ -122,7 +127,7 @@ class VGGFeatureExtractor(nn.Module):
                 return m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2))
             return isinstance(m, nn.ReLU)
         return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and
-                not torch.is_autocast_enabled('cuda') and all(ok(m) for m in self.vgg_net._modules.values()) and
+                (not torch.is_autocast_enabled('cuda') or _bf16_autocast()) and all(ok(m) for m in self.vgg_net._modules.values()) and
                 all(n.startswith('relu') for n in self.layer_name_list))
 
     def forward(self, x):

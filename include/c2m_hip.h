@@ -55,7 +55,9 @@ int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device,
  * kernel ids (C2M_KERNEL_*) and clears the list.  Off by default; costs two event records per call when on.
  */
 enum { C2M_KERNEL_CORR_MFMA = 1, C2M_KERNEL_CORR_GENERIC = 2, C2M_KERNEL_DCN_FWD = 3, C2M_KERNEL_DCN_BWD_DATA = 4,
-       C2M_KERNEL_DCN_BWD_WEIGHT = 5, C2M_KERNEL_CONV3X3 = 6 };
+       C2M_KERNEL_DCN_BWD_WEIGHT = 5, C2M_KERNEL_CONV3X3 = 6 /* fp32-MFMA direct / Winograd kernels */,
+       C2M_KERNEL_CONV3X3_SPLIT = 7 /* split-bf16 kernel (C2M_CONV_SPLIT_BF16X3 / C2M_CONV_BF16) */,
+       C2M_KERNEL_CONV3X3_WGRAD = 8 };
 enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LEAKY_RELU = 2 };   /* fused activations of the decoder-path entry points */
 int c2m_profile_enable(int on);
 int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
@@ -250,6 +252,23 @@ int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int
 size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3 or 1; 0 if unsupported (Cin % 16) */
 int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
+
+/*
+ * Backward of the same convolution (stage-3 training, ref_restoration_model.py:192-269; the reference leaves it to cuDNN).
+ *   data gradient:   dX = conv3x3(dY, W') with W'[ci][co][dy][dx] = W[co][ci][2-dy][2-dx] -- run c2m_conv3x3_nhwc_f32 with
+ *                    Cin' = Cout, Cout' = Cin and `wr` from c2m_conv3x3_relayout_split_dgrad_f32 (same image format as
+ *                    c2m_conv3x3_relayout_split_f32(Cout, Cin, pieces); size c2m_conv3x3_relayout_split_bytes(Cout, Cin, pieces));
+ *   weight gradient: dW[co][ci][dy][dx] = sum_{b,y,x} dY[b][y][x][co] * X[b][y+dy-1][x+dx-1][ci] on channels-last tensors
+ *                    (X = cat of one or two sources, each a multiple of 32 channels; pitches in floats, multiples of 4):
+ *                    fp32 MFMA, contraction split over pixel segments, partial sums in `workspace`, summed without atomics
+ *                    (deterministic).  grad_weight [Cout][Cin][3][3] is overwritten.
+ */
+int c2m_conv3x3_relayout_split_dgrad_f32(c2m_stream_t stream, const float* weight /* [Cout][Cin][3][3] */, int Cin, int Cout,
+                                         int pieces, void* wr);
+size_t c2m_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int c2m_conv3x3_wgrad_f32(c2m_stream_t stream, const c2m_conv_src* src, int nsrc, const float* grad_out, int g_pix_pitch,
+                          int g_row_pitch, long long g_img_pitch, int B, int H, int W, int Cin, int Cout, float* grad_weight,
+                          void* workspace, size_t workspace_bytes);
 
 /*
  * First layer of an image tower -- 3 input channels, 64 output channels (vgg conv1_1, vgg_arch.py:107-123; conv_first,

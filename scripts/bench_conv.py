@@ -65,7 +65,7 @@ def main():
             c2m_amd.profile_enable(False)
             continue
         torch.cuda.synchronize()
-        ms = [t for (n, t) in c2m_amd.profile_collect() if n == "conv3x3_mfma"]
+        ms = [t for (n, t) in c2m_amd.profile_collect() if n in ("conv3x3_mfma", "conv3x3_split")]
         c2m_amd.profile_enable(False)
         ms = sum(ms) / args.iters    # per call (a DCN head is two launches)
         fl = 2.0 * co * 9 * sum(cins) * hw * hw * B

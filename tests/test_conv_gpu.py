@@ -420,3 +420,59 @@ def test_weight_cache_refresh_follows_data_writes(ops, dev):
         assert float((b2 - 2 * a).abs().max()) < 1e-5 * float(a.abs().max())
         w.data.mul_(0.5)
         ops.refresh_weight_caches([w])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward: data gradient (split kernel on rotated / transposed weights), weight gradient (csrc/conv3x3_wgrad.hip), the
+# autograd Function around them -- against float64 autograd of F.conv2d
+# ---------------------------------------------------------------------------------------------------------------------
+GRAD_CASES = [
+    # B, [Cin per source], Cout, H, W, act
+    (2, [64], 64, 40, 40, 1),          # body conv1 at the stage-3 training size (LR 40), ReLU
+    (2, [64], 64, 37, 45, 0),          # ragged segments
+    (1, [64, 256], 256, 20, 24, 2),    # small_offset_conv1: two sources, LeakyReLU
+    (1, [64], 216, 12, 40, 0),         # DCN offset/mask head: Cout not a multiple of 16 (padded data-gradient conv)
+    (2, [64, 64], 64, 33, 70, 2),      # head_large geometry, three x segments
+    (1, [32], 32, 8, 5, 0),            # one 32-channel block, map smaller than a segment
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_conv3x3_autograd_matches_fp64_conv2d_gradients(ops, dev, case):
+    """gradients of act(conv3x3(cat(srcs)) + bias) w.r.t. every source, the weight and the bias against
+    float64 autograd through F.conv2d, at 1e-5 * scale of each gradient."""
+    B, cins, Cout, H, W, act = case
+    xs = [_cl(_rand((B, c, H, W), dev, 410 + k)).requires_grad_(True) for k, c in enumerate(cins)]
+    w = _rand((Cout, sum(cins), 3, 3), dev, 420, 1.0 / np.sqrt(9 * sum(cins))).requires_grad_(True)
+    b = _rand((Cout,), dev, 421).requires_grad_(True)
+    gy = _rand((B, Cout, H, W), dev, 422)
+    y = ops.conv3x3_autograd(xs, w, b, act=act, slope=0.1)
+    y.backward(gy)
+    xs64 = [x.detach().double().requires_grad_(True) for x in xs]
+    w64, b64 = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    y64 = F.conv2d(torch.cat(xs64, 1), w64, b64, padding=1)
+    y64 = y64.clamp_min(0) if act == 1 else torch.where(y64 > 0, y64, y64 * 0.1) if act == 2 else y64
+    y64.backward(gy.double())
+    assert float((y.double() - y64).abs().max()) < 1e-5 * max(1.0, float(y64.abs().max()))
+    for name, got, want in [("w", w.grad, w64.grad), ("b", b.grad, b64.grad)] + [(f"x{k}", x.grad, x64.grad) for k, (x, x64) in enumerate(zip(xs, xs64))]:
+        scale = max(1e-6, float(want.abs().max()))
+        err = float((got.double() - want).abs().max())
+        assert err < 1e-5 * scale, (name, err, scale)
+
+
+def test_conv3x3_wgrad_and_dgrad_entry_points(ops, dev):
+    """The two backward entry points on their own, with a strided (bordered) source and a grad_out that is a channel-slice view."""
+    B, C, Co, H, W = 2, 64, 64, 24, 40
+    bo = ops._bordered_empty(B, C, H, W, dev)
+    x = bo.interior()
+    x.copy_(_rand((B, C, H, W), dev, 430))
+    big = _cl(_rand((B, 2 * Co, H, W), dev, 431))
+    g = big[:, Co:]
+    w = _rand((Co, C, 3, 3), dev, 432, 0.05)
+    gw = ops.conv3x3_wgrad([x], g, Co)
+    dx = ops.conv3x3_dgrad(g, w)
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(x64, w64, None, padding=1).backward(g.double().contiguous())
+    assert float((gw.double() - w64.grad).abs().max()) < 1e-5 * float(w64.grad.abs().max())
+    assert float((dx.double() - x64.grad).abs().max()) < 1e-5 * float(x64.grad.abs().max())

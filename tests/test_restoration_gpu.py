@@ -368,3 +368,178 @@ def test_cfg5_320_bf16_autocast_psnr_budget(dev):
     assert 15.0 < p32 < 60.0, p32   # a real restoration quality, not a degenerate image
     assert abs(p16 - p32) <= 0.02, f"PSNR fp32 {p32:.4f} dB vs bf16 {p16:.4f} dB"
     assert abs(y16 - y32) <= 0.02, f"PSNR_Y fp32 {y32:.4f} dB vs bf16 {y16:.4f} dB"
+
+
+def test_cfg5_dynagg_layers_vs_oracle_and_bf16_residual(dev):
+    """BASELINE configs[4] shapes (LR 320x320: DynAgg layers at 320^2 x 256, 640^2 x 128, 1280^2 x 64), VERDICT r2 3(b):
+    (1) the three DynAgg outputs of the fp32 forward against the oracle DCNv2 on the FULL maps, from the offsets / masks
+    the head kernel produces for the same inputs (2e-5 * scale, the DCNv2 tests' tolerance);
+    (2) the bf16-autocast decoder (single-piece bf16 convolutions, same index map and Ref features) against the fp32 one on
+    the restoration RESIDUAL sr - bilinear(lq), which is what the network computes: relative 2-norm error within 3e-2 (bf16
+    has 8 mantissa bits: ~4e-3 per rounding, accumulated over ~100 layers), where a PSNR-vs-GT budget alone would pass with a
+    badly wrong residual."""
+    import c2m_amd
+    import c2m_oracle as oracle
+    ops = c2m_amd.ops
+    ext, mp, g = _build_chain(dev)
+    H = 1280
+    gt = _smooth_gt(1, H, 6100).to(dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    ref = torch.zeros((1, 3, H, H), device=dev)
+    ref[:, :, :500, :500] = _smooth_gt(1, 512, 6102)[:, :, :500, :500].to(dev)
+    for stage in ("small", "medium", "large"):   # live offset heads (the golden fill zeroes nothing, but make it explicit)
+        head = getattr(g.dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask
+        assert float(head.weight.abs().max()) > 0
+    cap = {}
+    hooks = [getattr(g.dyn_agg_restore, f"{s}_dyn_agg").register_forward_hook(
+        lambda m, i, o, s=s: cap.__setitem__(s, (i[0][0], i[0][1], i[1], o))) for s in ("small", "medium", "large")]
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        assert g._use_fused(lq, pre, ref_feat)
+        sr32 = g(lq, pre, ref_feat)
+        cap32 = dict(cap)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert g._use_fused(lq, pre, ref_feat)
+            sr16 = g(lq, pre, ref_feat)
+    for h_ in hooks:
+        h_.remove()
+    oracle.set_num_threads(64)
+    for stage in ("small", "medium", "large"):
+        refb, feat, fpre, out = cap32[stage]
+        m = getattr(g.dyn_agg_restore, f"{stage}_dyn_agg")
+        with torch.no_grad():
+            off, msk = ops.conv3x3_dcn_head(feat, m.conv_offset_mask.weight, m.conv_offset_mask.bias, 8, fpre.flow, fpre.scale)
+        x = refb.interior().contiguous().cpu().numpy()
+        want = oracle.dcn_v2_forward(x, m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), off.cpu().numpy(),
+                                     msk.cpu().numpy(), (1, 1), (1, 1), (1, 1), 8)
+        got = out.contiguous().cpu().numpy()
+        got = np.where(got > 0, got, got / np.float32(0.1))      # the fused path folds LeakyReLU(0.1) into the warp
+        err = float(np.abs(got - want).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(want).max())), (stage, err)
+        del x, want, got, off, msk
+    base = torch.nn.functional.interpolate(lq, None, 4, "bilinear", False)
+    r32, r16 = sr32 - base, sr16.float() - base
+    rel = float((r16 - r32).norm() / r32.norm())
+    assert float(r32.abs().max()) > 1e-3            # the residual is not degenerate
+    assert rel < 3e-2, rel
+
+
+def _train_opt(dist_on):
+    return {"dist": dist_on, "gpu_ids": [0], "is_train": True, "path": {},
+            "network_g": {"type": "RestorationNet", "ngf": 64, "n_blocks": 2, "groups": 8},
+            "network_map": {"type": "CorrespondenceGenerationArch", "patch_size": 3, "stride": 1,
+                            "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
+            "network_extractor": {"type": "ContrasExtractorSep"},
+            "train": {"lr_g": 1e-4, "lr_offset": 1e-4, "lr_relu2_offset": 1e-5, "lr_relu3_offset": 1e-6,
+                      "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0}}
+
+
+def _train_batch(B=2, h=16, seed=4000):
+    import synth
+    gt = torch.from_numpy(synth.uniform((B, 3, 4 * h, 4 * h), seed, 0.0, 1.0))
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
+    ref = torch.from_numpy(synth.uniform((B, 3, 4 * h, 4 * h), seed + 1, 0.0, 1.0))
+    return {"img_in_lq": lq, "img_ref": ref, "img_in": gt, "img_in_up": up}
+
+
+def test_ddp_nccl_wrapped_net_g_step_and_test_match_the_bare_module(dev):
+    """VERDICT r2 item 2 / ADVICE r2 (high): the REAL net_g (DCNv2 autograd function, live offset heads) wrapped by
+    model_to_device in DistributedDataParallel over RCCL (world size 1 on this box, gradient_as_bucket_view=True), fed the
+    lazy PreOffsets dict through DDP's input scatter: one optimize_parameters() step gives the bare module's gradients, and
+    test() -- the fused inference path behind the wrapper -- the bare module's output."""
+    import socket
+    import torch.distributed as dist
+    from mmsr.models.base_model import unwrap
+    from mmsr.models.ref_restoration_model import RefRestorationModel
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(11)
+        bare = RefRestorationModel(_train_opt(False))
+        for stage in ("small", "medium", "large"):
+            torch.nn.init.normal_(getattr(unwrap(bare.net_g).dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask.weight, std=0.01)
+        wrapped = RefRestorationModel(_train_opt(True))
+        assert isinstance(wrapped.net_g, torch.nn.parallel.DistributedDataParallel)
+        for dst, src in ((wrapped.net_g.module, bare.net_g), (wrapped.net_map, bare.net_map), (wrapped.net_extractor, bare.net_extractor)):
+            dst.load_state_dict(unwrap(src).state_dict())
+        data = _train_batch()
+        for m in (bare, wrapped):
+            m.feed_data(data)
+        out_b, out_w = bare.test(), wrapped.test()
+        assert float((out_b - out_w).abs().max()) < 1e-6
+        bare.optimize_parameters(1)
+        wrapped.optimize_parameters(1)
+        torch.cuda.synchronize()
+        assert abs(float(wrapped.log_dict["l_g_pix"]) - float(bare.log_dict["l_g_pix"])) < 1e-6
+        n = 0
+        for (k, pb), (_, pw) in zip(unwrap(bare.net_g).named_parameters(), wrapped.net_g.module.named_parameters()):
+            if pb.grad is None:
+                assert pw.grad is None, k
+                continue
+            scale = max(1e-12, float(pb.grad.abs().max()))
+            assert float((pb.grad - pw.grad).abs().max()) <= 1e-5 * scale, k    # (DCNv2 weight grads use fp32 atomics)
+            n += 1
+        assert n > 50
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dataparallel_scatter_keeps_the_fused_path(dev):
+    """nn.DataParallel (the reference's default without a launcher, base_model.py:73-74) rebuilds dict inputs per replica:
+    PreOffsets must come out as PreOffsets (sliced index map), so the replica still takes the fused path."""
+    ext, mp, g = _build_chain(dev)
+    data = _train_batch(B=2, h=24, seed=4100)
+    lq, up, ref = (data[k].to(dev) for k in ("img_in_lq", "img_in_up", "img_ref"))
+    dp = torch.nn.DataParallel(g, device_ids=[0])
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        want = g(lq, pre, ref_feat)
+        got = dp(lq, pre, ref_feat)
+    assert list(pre.keys()) == ["max_idx"]             # nothing was materialised on the way
+    assert float((got - want).abs().max()) < 1e-6
+
+
+def test_training_path_on_hand_written_kernels_matches_stock_modules(dev):
+    """Gradients enabled: RestorationNet runs its 3x3 convolutions forward and backward on the hand-written kernels
+    (ops.conv3x3_autograd).  Same weights, same inputs: output and every parameter gradient agree with the stock
+    module-by-module path (allow_fused = False: MIOpen convolutions) to the accuracy of the latter."""
+    import c2m_amd
+    ext, mp, g = _build_chain(dev)
+    for stage in ("small", "medium", "large"):
+        torch.nn.init.normal_(getattr(g.dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask.weight, std=0.01)
+    data = _train_batch(B=2, h=24, seed=4200)
+    lq, up, ref, gt = (data[k].to(dev) for k in ("img_in_lq", "img_in_up", "img_ref", "img_in"))
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+
+    def run(fused):
+        g.allow_fused = fused
+        g.zero_grad(set_to_none=True)
+        assert g._use_train_kernels(lq, ref_feat) == fused
+        c2m_amd.profile_enable(True)
+        c2m_amd.profile_collect()
+        out = g(lq, pre, ref_feat)
+        (out - gt).abs().mean().backward()
+        torch.cuda.synchronize()
+        names = {n for n, _ in c2m_amd.profile_collect(capacity=65536)}
+        c2m_amd.profile_enable(False)
+        return out.detach(), {k: p.grad.detach().clone() for k, p in g.named_parameters() if p.grad is not None}, names
+
+    out_s, grads_s, names_s = run(False)
+    out_k, grads_k, names_k = run(True)
+    g.allow_fused = True
+    assert {"conv3x3_split", "conv3x3_wgrad"} <= names_k and "conv3x3_wgrad" not in names_s
+    assert float((out_k - out_s).abs().max()) < 1e-4
+    assert grads_k.keys() == grads_s.keys() and len(grads_k) > 200
+    worst = 0.0
+    for k in grads_s:
+        scale = max(1e-9, float(grads_s[k].abs().max()))
+        worst = max(worst, float((grads_k[k] - grads_s[k]).abs().max()) / scale)
+    assert worst < 2e-3, worst     # (the stock path itself is MIOpen Winograd / atomics: ~1e-4 relative)
