@@ -165,10 +165,11 @@ using namespace c2m;
 
 namespace {
 int wgrad_slices(long long nseg, int Cin, int Cout) {
-  // ~1024 workgroups per launch (256 CUs x 4 resident), at least 4 segments per workgroup
+  // ~768 workgroups per launch (256 CUs x 3 resident) but at least 8 segments each: every slice costs a partial image of
+  // Cout x Cin x 9 floats written and read again (at 1024 slices that traffic, not the MFMAs, set the kernel's time)
   const long long blocks = (long long)(Cin / conv::wgrad::XCI) * ((Cout + conv::wgrad::GCO - 1) / conv::wgrad::GCO);
-  long long s = (1024 + blocks - 1) / blocks;
-  s = std::min<long long>(s, (nseg + 3) / 4);
+  long long s = (768 + blocks - 1) / blocks;
+  s = std::min<long long>(s, (nseg + 7) / 8);
   return (int)std::max<long long>(1, s);
 }
 }  // namespace

@@ -58,6 +58,20 @@ class ContentExtractor(nn.Module):
         return _fused_body(self.body, f)
 
 
+import os as _os
+
+#: $C2M_TRAIN_KERNELS: "1" always run the training step's convolutions on the hand-written kernels, "0" never (stock
+#: modules = MIOpen), "auto" (default) from TRAIN_KERNELS_MIN_PIXELS LR pixels per batch on
+_TRAIN_KERNELS = _os.environ.get("C2M_TRAIN_KERNELS", "auto")
+TRAIN_KERNELS_MIN_PIXELS = 4 * 96 * 96
+
+
+def _train_kernels_wanted(x):
+    if _TRAIN_KERNELS in ("0", "1"):
+        return _TRAIN_KERNELS == "1"
+    return x.shape[0] * x.shape[2] * x.shape[3] >= TRAIN_KERNELS_MIN_PIXELS
+
+
 def _has_hooks(module):
     return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
 
@@ -235,6 +249,8 @@ class RestorationNet(nn.Module):
         kernels (ops.conv3x3_autograd) for fp32 GPU inputs outside autocast; `allow_fused = False` or forward hooks on inner
         modules keep the stock module-by-module path."""
         if not (self.allow_fused and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+            return False
+        if not _train_kernels_wanted(x):
             return False
         if torch.is_autocast_enabled('cuda') or self.dyn_agg_restore.has_inner_hooks() or _has_hooks(self.content_extractor):
             return False
