@@ -457,8 +457,10 @@ def test_ddp_nccl_wrapped_net_g_step_and_test_match_the_bare_module(dev):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
+    import mmsr.models.archs.ref_restoration_arch as arch
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-    try:
+    arch._TRAIN_KERNELS = "1"   # the hand-written (deterministic) convolution kernels at this small size too: bare and wrapped
+    try:                        # runs must then agree to rounding (two MIOpen runs of one net need not)
         torch.manual_seed(11)
         bare = RefRestorationModel(_train_opt(False))
         for stage in ("small", "medium", "large"):
@@ -486,6 +488,7 @@ def test_ddp_nccl_wrapped_net_g_step_and_test_match_the_bare_module(dev):
             n += 1
         assert n > 50
     finally:
+        arch._TRAIN_KERNELS = "auto"
         dist.destroy_process_group()
 
 
