@@ -782,6 +782,8 @@ def refresh_weight_caches(module_or_params=None):
     this once per forward: in-place writes through ``param.data`` do not bump the version counter the caches are keyed
     on, so without it such an update would keep computing with the old weights.  Returns the number of
     images rebuilt.  No host synchronisation."""
+    if _os.environ.get("C2M_WEIGHT_REFRESH", "1") == "0":   # measurement only: what the per-forward refresh costs
+        return 0
     ids = None
     if module_or_params is not None:
         params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
@@ -877,7 +879,7 @@ def vgg_stack_forward(layers, x, taps=(), mean=None, std=None, last_nchw=False, 
     B, C, H, W = x.shape
     dev = x.device
     # cached weight images follow in-place writes through .data (which the version counter does not see)
-    _wcache.refresh({id(p_) for layer_ in layers.values() for p_ in layer_.parameters()})
+    refresh_weight_caches([p_ for layer_ in layers.values() for p_ in layer_.parameters()])
     first = layers[names[0]]
     rgb64 = C == 3 and isinstance(first, torch.nn.Conv2d) and tuple(first.weight.shape) == (64, 3, 3, 3)
     if rgb64:

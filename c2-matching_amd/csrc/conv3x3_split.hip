@@ -14,24 +14,28 @@
 // only w0x0 with round-to-nearest pieces: the plain bf16 convolution of BASELINE configs[4] (bf16 inference), 1/6 of the
 // matrix work again.
 //
-// Mapping (one workgroup = 4 waves = one wave per SIMD, 32 x 8 output pixels x MW = 32*MT output channels):
+// Mapping (one workgroup = 4 waves, TWO workgroups per CU = two waves per SIMD; 32 x 8 output pixels x MW = 32*MT couts):
 //   * wave w owns pixel rows 2w, 2w+1 of the tile: NT = 2 pixel tiles x MT channel tiles = 2*MT accumulators f32x16;
-//   * K is swept in chunks of 16 input channels (= K of one MFMA).  The zero-padded 34 x 10 halo tile of a chunk arrives
-//     as fp32 by LDS-DMA (buffer_load ... lds, hardware zero fill outside the image) into `raw`; every wave then splits
-//     the pieces it fetched itself (no barrier between DMA and split) into NP bf16 planes laid out [plane][k half][pixel]
-//     [8 bf16]: a B operand (8 channels of one pixel) is one ds_read_b128, 16 consecutive lanes read 256 contiguous
-//     bytes for any tap shift (conflict-free without a swizzle).  The split of chunk c+1 (22 VALU + 4 LDS instructions
-//     per 4 channels x pixel) is interleaved with the MFMAs of chunk c -- bf16 MFMAs leave ~5 issue slots per instruction
-//     free -- and the planes are double buffered;
-//   * weights are split once per weight version on the host side of the call (conv3x3_relayout_split_kernel) into
-//     ready-made LDS images [cout block][chunk][dy][dx][plane][mt][k half][32 rows][8 bf16]; a unit = one kernel row
-//     (3 taps, 3*NP*MT KiB) streams by linear DMA into a ring of 3 slots, two units ahead of its use;
-//   * per tap: NP*MT A reads + NP*NT B reads (ds_read_b128) feed NPROD*MT*NT MFMAs (24 for the fp32 flavour), operands
-//     fetched one tap ahead into a second register set; one barrier per unit (72 MFMAs);
+//   * K is swept in chunks of 16 input channels (= K of one MFMA).  Per chunk, phase (A): the zero-padded 34 x 10 halo tile
+//     arrives as fp32 in REGISTERS (buffer_load_dwordx4 with hardware zero fill outside the image, issued a whole chunk
+//     ahead; 6 pieces per wave), every wave splits its pieces (22 VALU per 4 channels x pixel) into NP bf16 planes in LDS laid
+//     out [plane][k half][pixel][8 bf16]: a B operand (8 channels of one pixel) is one ds_read_b128, 16 consecutive lanes
+//     read 256 contiguous bytes for any tap shift (conflict-free without a swizzle).  The planes are single-buffered: while
+//     one workgroup splits, the co-resident one owns the matrix pipe;
+//   * phase (B): three units (kernel rows) of three taps.  Weights are split once per weight version on the host side of
+//     the call (conv3x3_relayout_split_kernel) into ready-made LDS images [cout block][chunk][dy][dx][plane][mt][k half]
+//     [32 rows][8 bf16]; a unit's image (3*NP*MT KiB) streams by LDS-DMA into a ring of 2 slots one unit ahead, its pieces
+//     issued one per MFMA group of the previous unit's first tap; one barrier per unit;
+//   * per tap: NP*MT A reads + NP*NT B reads (ds_read_b128, hand-placed: inline asm between sched_barrier fences, one tap
+//     ahead into the other of two register sets) feed NPROD*MT*NT MFMAs (24 for the fp32 flavour);
 //   * persistent tiles, XCD-aware tile order, epilogue in registers with the store flavours of conv3x3.hip (channels-last
 //     (+ residuals), PixelShuffle(2), planar NCHW, DCN offset/mask head) plus ReLU + MaxPool2d(2,2) (both rows of a
 //     pooling window live in one lane, the horizontal neighbour one lane over).
-// LDS: raw 24 KiB + planes 2 x 36.75 KiB + weight ring 3 x 18 KiB + 1.25 KiB = 152.75 KiB (NP = 3, MT = 2).
+// LDS: planes 36.75 KiB + weight ring 2 x 18 KiB + 1.25 KiB = 74 KiB (NP = 3, MT = 2); <= 256 registers.
+// How it got here: v1 LDS-DMA for halo and weights, one workgroup per CU (2.78 ms on the 64->64 @640^2 B=16
+// layer); v3 weights by per-wave buffer loads, halo through registers, two workgroups per CU (2.4-2.5 ms; the per-wave weight
+// loads quadrupled the L2 traffic); v4 (this file) weights once per workgroup through LDS again (2.3-2.4 ms, MFMA pipe 73 %
+// busy at the ~1.55 GHz the chip sustains under this load).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -166,11 +170,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   using PR = Products<NP>;
   constexpr int PLB = NP * 2 * HALFB;           // bytes of one plane buffer
   constexpr int WTAP = NP * MT * 1024;          // one tap's weight image: [plane][mt][half][32 rows][16 B]
-  constexpr int WUNIT = 3 * WTAP;               // one kernel row
+  constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
+  constexpr int NWI = WUNIT / 1024;             // LDS-DMA instructions per unit
+  constexpr int NW_W = (NWI + 3) / 4;           // per wave (the last wave pads with dummies: uniform vmcnt counts)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  // [planes x2 | bias MW floats]
+  // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned pl_base = lds0, bias_lds = lds0 + 2 * PLB;
+  const unsigned pl_base = lds0, w_base = lds0 + PLB, dummy = w_base + 2 * WUNIT, bias_lds = dummy + 1024;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,28 +187,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   const int UT = p.nchunks * 3;         // units per tile
   const int G = ntl * p.nchunks;        // chunks of this workgroup
 
-  // ---- weights: never staged in LDS.  The A operand of (chunk, dy, dx, plane, mt) is 1 KiB contiguous in the re-laid-out
-  // weights (lane (hi, j): 16 bytes at hi*512 + j*16): one buffer_load_dwordx4 per operand straight into the registers the
-  // MFMA reads, issued TWO taps ahead of its use (LDS-DMA costs ~100 issue cycles per KiB on this chip -- with one wave per
-  // SIMD that is matrix time -- and the weight stream is 70 % of this kernel's fills).  The four waves read the same
-  // lines: one L2 fetch, three L1 hits.  soffset = byte offset of the tap inside this cout block's weights (wraps per tile).
-  const i32x4 wrs = make_rsrc_words(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
-  const unsigned wvoff0 = hi * 512 + j * 16, wvoff1 = wvoff0 + 4096;
-  int wsoff = 0;   // tap the NEXT load_a() call fetches
-  bf16x8 A[3][NP][MT], Bq[3][NP][NT];   // operand sets, one per kernel column dx
-  auto load_a_piece = [&](auto dxc, auto kc) __attribute__((always_inline)) {   // operand K = pl*MT + mt of the tap at wsoff -> set DX
-    constexpr int DX = decltype(dxc)::value, K = decltype(kc)::value;
-    if constexpr (K < 4) buf_load128<K * 1024>(A[DX][K / MT][K % MT], wvoff0, wrs, wsoff);
-    else buf_load128<(K - 4) * 1024>(A[DX][K / MT][K % MT], wvoff1, wrs, wsoff);
+  // ---- weights: one fetch per WORKGROUP.  Unit u of this cout block (= kernel row dy of a chunk, WUNIT contiguous bytes of the
+  // re-laid-out weights) streams by LDS-DMA into ring slot u & 1 while unit u-1 is being multiplied; wave w moves
+  // instructions [w*NW_W, (w+1)*NW_W).  (Round-3 measurements: every wave loading its own A operands straight from L2
+  // quadruples the weight traffic -- 15 TB/s of L2 reads at full rate -- and cost 16 % of the kernel's time.)
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
+  const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
+  int wsoff = 0;   // unit the NEXT issue fetches (wraps per tile)
+  auto issue_w_piece = [&](unsigned slot_off, int i) __attribute__((always_inline)) {
+    const int n = wv * NW_W + i;
+    const unsigned dst = n < NWI ? w_base + slot_off + n * 1024 : dummy;
+    // (beyond the image: reads the next unit / zeros past the end of the buffer, lands in the dummy page)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff + i * 1024, 0, 0);
   };
-  auto load_a_done = [&]() __attribute__((always_inline)) {
-    wsoff += WTAP;
+  auto issue_w_done = [&]() __attribute__((always_inline)) {
+    wsoff += WUNIT;
     if (wsoff == UT * WUNIT) wsoff = 0;
   };
 
   // ---- halo tile: 24 slots of 64 pieces (pixel, 4 fp32 channels); slot r of wave wv = pieces [64 (wv + 4r), +64), fetched
   // by buffer_load_dwordx4 (hardware zero fill outside the image) into a register that stays with the wave until split round
-  // r of that chunk has consumed it -- a whole chunk later
+  // r of that chunk consumes it -- a whole chunk later
   struct TileCoord { int b, ty, tx; };
   auto tc_init = [&](int tile) __attribute__((always_inline)) {
     TileCoord t;
@@ -266,10 +271,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     else buf_load128f(rawr[sl], ivoff[sl], rs1, in_soff);
   };
 
-  // ---- split of the wave's own raw pieces into the bf16 planes of buffer `nb`.  Round r: piece 64 (wv + 4r) + l =
-  // (pixel 16 (wv + 4r) + (l >> 2), quad q = l & 3) -> plane slab (q >> 1), 8 bytes at pixel*16 + (q & 1)*8.
-  const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;   // + r * 1024 + plane * 2*HALFB + nb * PLB
-  u32x2 cq[3];   // the split pieces of the current round, between the group that forms them and the group that stores them
+  // ---- split of the wave's own raw pieces into the bf16 planes.  Round r: piece 64 (wv + 4r) + l = (pixel 16 (wv + 4r) +
+  // (l >> 2), quad q = l & 3) -> plane slab (q >> 1), 8 bytes at pixel*16 + (q & 1)*8.
+  const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;   // + r * 1024 + plane * 2*HALFB
+  u32x2 cq[3];
   auto conv_split = [&](const f32x4 v) __attribute__((always_inline)) {
     if constexpr (NP == 3) {
       split3(v, cq[0], cq[1], cq[2]);
@@ -281,21 +286,28 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       cq[0] = __builtin_bit_cast(u32x2, h);
     }
   };
-  auto conv_store = [&](auto rr, unsigned dst) __attribute__((always_inline)) {   // dst = cdst + buffer offset
+  auto conv_store = [&](auto rr) __attribute__((always_inline)) {
     constexpr int R = decltype(rr)::value;
-    lds_write64<R * 1024>(dst, cq[0]);
+    lds_write64<R * 1024>(cdst, cq[0]);
     if constexpr (NP == 3) {
-      lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
-      lds_write64<R * 1024 + 4 * HALFB>(dst, cq[2]);
+      lds_write64<R * 1024 + 2 * HALFB>(cdst, cq[1]);
+      lds_write64<R * 1024 + 4 * HALFB>(cdst, cq[2]);
     }
   };
 
-  // ---- B operand: pixel (row 2wv + nt + dy, column j + dx) of the halo tile, k half hi, plane pl, buffer nb
+  // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, plane pl, channel tile mt;
+  //                B = pixel (row 2wv + nt + dy, column j + dx) of the halo tile, k half hi, plane pl
+  const unsigned abase = w_base + hi * 512 + j * 16;
   const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
-  constexpr int NLB = NP * NT, NLA = NP * MT;       // B reads (LDS) / A loads (L1/L2) per tap
-  auto load_b = [&](auto dyc, auto dxc, auto kc, unsigned bsrc) __attribute__((always_inline)) {   // read K of tap (DY, DX) -> set DX
-    constexpr int DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
-    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[DX][K / NT][K % NT], bsrc);
+  bf16x8 A[2][NP][MT], Bq[2][NP][NT];   // two operand sets: tap (dy, dx) multiplies set (dy + dx) & 1
+  constexpr int NLB = NP * NT, NLA = NP * MT;
+  auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {   // aslot = abase + ring slot offset
+    constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<DX * WTAP + K * 1024>(A[SET][K / MT][K % MT], aslot);
+  };
+  auto load_b = [&](auto setc, auto dyc, auto dxc, auto kc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bbase);
   };
 
   const int co_lane = cb * MW + 4 * hi;
@@ -312,89 +324,97 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
   // ------------------------------------------------------------------------------------------------------------------
-  // prologue: chunk 0 is fetched, split and published before the first MFMA; the weights of taps 0 and 1 and the raw
-  // pieces of chunk 1 are in flight
+  // prologue: the raw pieces of chunk 0 and the weights of unit 0
   // ------------------------------------------------------------------------------------------------------------------
   issue_in_begin();
   static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
-  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
-    constexpr int R = decltype(rr)::value;
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rawr[R]) : "n"(NRAW_W - 1 - R));
-    conv_split(rawr[R]);
-    conv_store(rr, cdst);
-  });
-  if (G > 1) {
-    issue_in_begin();
-    static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
-  }
-  static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) { load_a_piece(std::integral_constant<int, 0>(), kc); });
-  load_a_done();
-  static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) { load_a_piece(std::integral_constant<int, 1>(), kc); });
-  load_a_done();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
-    load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, bbase);
-  });
+#pragma unroll
+  for (int i = 0; i < NW_W; ++i) issue_w_piece(0u, i);
+  issue_w_done();
+  wait_vmcnt<0>();
 
-  // One tap = PR::N groups of MT*NT MFMAs (one piece product each), fenced by sched_barriers so that everything else stays
-  // where it is written.  Per tap: the NLB B reads of the next tap (LDS, first groups), the NLA A loads of the tap after next
-  // (one per group), on six of the nine taps one split round of the next chunk (VALU in the last group but one, its three
-  // stores in the last; the round's register is then re-loaded for the chunk after next).
-  // Waits at the top of a tap: lgkmcnt(0) -- every LDS operation of the previous tap, the youngest a group old; vmcnt(NLA) --
-  // all but the NLA loads issued during the previous tap, i.e. this tap's A operands (issued two taps ago) and every raw
-  // piece older than that.  Two barriers per chunk: after unit 1 (the split planes of the next chunk are complete) and
-  // after unit 2 (everybody has finished reading this chunk's planes: the next chunk may overwrite them).
+  // Per chunk: (A) every wave splits its raw pieces into the planes (single buffer: the co-resident workgroup owns the
+  // matrix pipe meanwhile) and re-loads the registers for the next chunk; barrier; (B) three units (kernel rows) of three taps.
+  // One tap = PR::N groups of MT*NT MFMAs, fenced by sched_barriers so that everything else stays where it is written: the
+  // first groups read the next tap's operands (two sets, one tap ahead; the A operands of a unit's FIRST tap are read after
+  // the barrier that publishes the unit's weights), the unit's first tap also issues the LDS-DMA pieces of the NEXT unit's
+  // weights, one per group.  Unit end: own LDS ops / DMAs done, barrier (publishes W(u+1), frees the planes / ring slot).
   constexpr int NG = PR::N;
-  constexpr int BPG = NG >= 4 ? (NLB + NG - 3) / (NG - 2) : NLB;    // B reads per group
-  constexpr int APG = (NLA + NG - 1) / NG;                          // A loads per group
+  constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NLA + NLB);   // operand reads per group
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const unsigned nb_cur = (gc & 1) ? PLB : 0u, nb_nxt = PLB - nb_cur;
-      const unsigned bcur = bbase + nb_cur, bnxt = bbase + nb_nxt, cnxt = cdst + nb_nxt;
-      const bool more_in = ABL != 2 && ABL < 7 && gc + 2 < G;   // the raw registers are re-loaded for chunk gc+2 as the rounds of chunk gc+1 free them
+      const bool more_in = ABL != 2 && gc + 1 < G;
+      // ---- (A) split
       if (more_in) issue_in_begin();
+      if constexpr (ABL != 3) {
+        static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
+          constexpr int R = decltype(rr)::value;
+          conv_split(rawr[R]);
+          conv_store(rr);
+          if (more_in) issue_in_piece(rr);    // same slot of the next chunk
+        });
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- (B) multiply
       static_for<0, 3>([&](auto dyc) __attribute__((always_inline)) {
         constexpr int dy = decltype(dyc)::value;
+        const int u = 3 * gc + dy;
+        const unsigned slot_cur = (u & 1) ? (unsigned)WUNIT : 0u, slot_nxt = (unsigned)WUNIT - slot_cur;
+        const unsigned aslot = abase + slot_cur;
+        const bool do_w = ABL != 1 && u + 1 < 3 * G;     // weights of unit u+1 -> the other ring slot
+        // operands of the unit's first tap: A now (its weights were published by the barrier just passed); B too at dy == 0
+        static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
+          load_a(std::integral_constant<int, (dy & 1)>(), std::integral_constant<int, 0>(), kc, aslot);
+        });
+        if constexpr (dy == 0) {
+          static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
+            load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc);
+          });
+        }
         static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
           constexpr int dx = decltype(dxc)::value;
-          constexpr int t = 3 * dy + dx;
-          constexpr bool conv = dy < 2 && ABL != 3 && ABL < 7;   // split round t of the NEXT chunk (units 0 and 1)
-          constexpr int ndx = (dx + 1) % 3, ndy = dx < 2 ? dy : (dy + 1) % 3;   // the next tap
-          constexpr int adx = (dx + 2) % 3;                                      // set of the tap after next
-          const unsigned bsrc = (dx == 2 && dy == 2) ? bnxt : bcur;
-          if constexpr (ABL < 7) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
+          constexpr int set = (dy + dx) & 1, nset = set ^ 1;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           static_for<0, NG>([&](auto gcnt) __attribute__((always_inline)) {
             constexpr int g = decltype(gcnt)::value;
-            if constexpr (ABL != 6 && ABL < 7) {
-              static_for<g * BPG, (g + 1) * BPG < NLB ? (g + 1) * BPG : NLB>([&](auto kc) __attribute__((always_inline)) {
-                load_b(std::integral_constant<int, ndy>(), std::integral_constant<int, ndx>(), kc, bsrc);
+            if constexpr (ABL != 6) {
+              // next tap's operands: (dy, dx+1): A and B; after the unit's last tap: only B of (dy+1, 0)
+              static_for<g * LPG, (g + 1) * LPG < NLA + NLB ? (g + 1) * LPG : NLA + NLB>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if constexpr (dx < 2) {
+                  if constexpr (K < NLA) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), kc, aslot);
+                  else load_b(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>());
+                } else if constexpr (dy < 2) {
+                  if constexpr (K >= NLA)
+                    load_b(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(),
+                           std::integral_constant<int, K - NLA>());
+                }
               });
             }
-            if constexpr (ABL != 1 && ABL < 7) {
-              static_for<g * APG, (g + 1) * APG < NLA ? (g + 1) * APG : NLA>([&](auto kc) __attribute__((always_inline)) {
-                load_a_piece(std::integral_constant<int, adx>(), kc);
-              });
-            }
-            if constexpr (conv && g == (NG >= 2 ? NG - 2 : 0)) conv_split(rawr[t < NRAW_W ? t : 0]);
-            if constexpr (conv && g == NG - 1) {
-              conv_store(std::integral_constant<int, (t < NRAW_W ? t : 0)>(), cnxt);
-              if (more_in) issue_in_piece(std::integral_constant<int, (t < NRAW_W ? t : 0)>());   // same slot of the chunk after next
+            if constexpr (dx == 0) {
+              if (do_w) {
+#pragma unroll
+                for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i);
+              }
             }
             if constexpr (ABL != 5) {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dx][PR::W[g]][mt], Bq[dx][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][PR::W[g]][mt], Bq[set][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
-          if constexpr (ABL != 1 && ABL < 7) load_a_done();
+          if constexpr (dx == 0) {
+            if (do_w) issue_w_done();
+          }
         });
-        if constexpr (dy >= 1 && ABL != 4 && ABL != 8) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own split stores / operand reads are done; then everybody's
+        if (ABL != 4 && (u + 1 < 3 * G || true)) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
         }
       });
@@ -567,7 +587,7 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
-  constexpr size_t ldsb = 2 * (size_t)(NP * 2 * split::HALFB) + 256;   // two plane buffers + bias
+  constexpr size_t ldsb = (size_t)(NP * 2 * split::HALFB) + 2 * (size_t)(3 * NP * MT * 1024) + 1024 + 256;   // planes, weight ring x2, dummy, bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {

@@ -56,12 +56,15 @@ busy = {}
 for k, c in summary.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]["sum"] > 0:
         busy[k] = (c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / 1024.0) / (c["GRBM_GUI_ACTIVE"]["sum"] / 8.0)
-conv = [k for k in summary if "conv3x3" in k and "relayout" not in k]
+conv_split = [k for k in summary if "conv3x3_split_kernel" in k]
+conv_mfma = [k for k in summary if "conv3x3" in k and "relayout" not in k and "split" not in k and "wgrad" not in k]
 dcn = [k for k in summary if "dcn_fwd" in k]
 corr = [k for k in summary if "corr_argmax_mfma_kernel" in k]
 out = {
     "workload": "bench.py default (configs[2], B=16, LR 160), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes",
-    "conv3x3_hbm_bytes_per_step": sum(hbm(k, "sum") or 0.0 for k in conv) / nsteps,
+    "measured_at": f"round-3 final pass ({tag}, scripts/gpu_final.sh)",
+    "conv3x3_split_hbm_bytes_per_step": sum(hbm(k, "sum") or 0.0 for k in conv_split) / nsteps,
+    "conv3x3_mfma_hbm_bytes_per_step": sum(hbm(k, "sum") or 0.0 for k in conv_mfma) / nsteps,
     "dcn_v2_forward_hbm_bytes_per_step": sum(hbm(k, "sum") or 0.0 for k in dcn) / nsteps,
     "dcn_v2_forward_hbm_bytes_per_launch": {k: hbm(k) for k in dcn},
     "corr_hbm_bytes_per_launch": hbm(corr[0]) if corr else None,
@@ -72,7 +75,8 @@ out = {
             "(GRBM_GUI_ACTIVE / 8 XCDs), summed over the launches of the run.",
 }
 json.dump(out, open(os.path.join(REPO, "profiles", "step_pmc_traffic.json"), "w"), indent=1)
-for name in ("bench_default", "bench_corr", "bench_conv", "bench_dcn", "bench_train", "pytest_gpu", "smoke"):
+for name in ("bench_default", "bench_corr", "bench_conv", "bench_dcn", "bench_train", "bench_train_lr96", "bench_train_rccl_1rank",
+             "bench_cfg5_bf16", "bench_cfg5_f32", "bench_selfspawn_1gpu", "ubench_mfma_bf16_rate", "pytest_gpu", "smoke"):
     src = os.path.join(SRC, name + ".log")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(REPO, "profiles", f"{tag}_{name}.log"))
