@@ -59,9 +59,12 @@ constexpr int NRAW_W = (NPIX * 4 + 255) / 256;  // 6 DMA instructions per wave: 
 constexpr int NRAW = 4 * NRAW_W;                // 24 slots (22 carry pixels; the rest read zeros) -- every wave runs the
                                                 // same branch-free sequence of DMAs and split rounds
 constexpr int RAW_BYTES = NRAW * 1024;
-constexpr int HALFB = NRAW * 256 + 128;         // one (plane, k half) slab: 384 pixels x 16 B + 128 (== 128 mod 256: the
-                                                // split's 8-byte stores of a half-wave then cover all 64 banks once)
-static_assert(HALFB % 256 == 128, "bank phase of the second k half");
+constexpr int HALFB = NRAW * 256 + 64;          // one (plane, k half) slab: 384 pixels x 16 B + 64.  ds_write_b64 is serviced in groups
+                                                // of 16 consecutive lanes over 32 banks ((a/4) mod 32, MI355X_MICROARCH.md): a group of
+                                                // the split's stores covers 4 pixels x 16 B in each k-half slab -- == 64 mod 128 puts the
+                                                // two slabs on disjoint banks (with == 0 they collided 2-way: SQ_LDS_BANK_CONFLICT was 12 %
+                                                // of the LDS-active cycles)
+static_assert(HALFB % 128 == 64 && HALFB % 16 == 0, "bank phase of the second k half");
 
 template <int NP> struct Products;
 template <> struct Products<1> { static constexpr int N = 1; static constexpr int W[1] = {0}; static constexpr int X[1] = {0}; };
