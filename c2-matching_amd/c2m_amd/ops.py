@@ -316,8 +316,8 @@ class _WeightCache:
         w = w.contiguous()
         L = _lib.lib()
         wino = int(wino)
-        if wino in (3, 4, 5):   # split-bf16 images (3 exact pieces / 1 rounded piece per weight); 5: of the data-gradient conv
-            pieces = 1 if wino == 4 else 3
+        if wino in (3, 4, 5, 6):   # split images (3 exact bf16 pieces / 1 rounded piece per weight; 6: scaled f16 x 2); 5: of the data-gradient conv
+            pieces = 1 if wino == 4 else 2 if wino == 6 else 3
             nbytes = L.c2m_conv3x3_relayout_split_bytes(Co, Ci, pieces) if wino == 5 else L.c2m_conv3x3_relayout_split_bytes(Ci, Co, pieces)
         else:
             nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
@@ -330,7 +330,7 @@ class _WeightCache:
             if wino == 5:
                 _lib.check(L.c2m_conv3x3_relayout_split_dgrad_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
                            "c2m_conv3x3_relayout_split_dgrad_f32")
-            elif wino in (3, 4):
+            elif wino in (3, 4, 6):
                 _lib.check(L.c2m_conv3x3_relayout_split_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
                            "c2m_conv3x3_relayout_split_f32")
             else:
@@ -338,7 +338,7 @@ class _WeightCache:
                 _lib.check(fn(_stream(), w.data_ptr(), Ci, Co, wr.data_ptr()), "c2m_conv3x3_relayout")
         return wr
 
-    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3), 3 split-bf16x3, 4 bf16
+    def get(self, weight, pad_cin_to=None, rows=None, wino=0):   # wino: 0 direct, 1 F(2,3), 2 F(4,3), 3 split-bf16x3, 4 bf16, 5 dgrad, 6 split-f16x2
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), pad_cin_to, weight.device.index)
         slot = (id(weight), rows, wino)
         hit = self._lookup(slot, key, weight)
@@ -376,10 +376,17 @@ _WINO4 = _os.environ.get("C2M_CONV_WINO4", "1") != "0"
 # configs[2]: 1 near-tie flip of 24 964 queries against the CPU chain, 2 with the fp32-MFMA kernels); "1" -- only calls
 # with fast=True (decoder, DCN heads, VGG taps of the Ref); "0" -- never (fp32-MFMA direct / Winograd kernels only)
 _SPLIT = _os.environ.get("C2M_CONV_SPLIT", "all")
-ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4}
-_FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16")
+# C2M_CONV_SPLIT16: "1" (default) -- where the split kernel is chosen automatically, inference runs its f16 x 2 flavour
+# (three f16 products per fp32 product sum instead of six bf16 ones; error of the class of an fp32 accumulation chain,
+# domain |x| < 65520: include/c2m_hip.h C2M_CONV_SPLIT_F16X2); "0" -- the bf16 x 3 flavour (full fp32 range) everywhere.
+# The autograd path (conv3x3_autograd: gradients can be tiny) always runs bf16 x 3.
+_SPLIT16 = _os.environ.get("C2M_CONV_SPLIT16", "1") != "0"
+# internal kernel ids (= weight-cache kinds; 5 is the data-gradient image of the bf16 x 3 kernel) -> c2m_conv3x3_desc.algo
+ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4, "split16": 6}
+_DESC_ALGO = (0, 1, 2, 3, 4, 3, 5)
+_FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16", "split_bf16x3", "split_f16x2")
 # matrix flops actually executed per algorithmic (direct-convolution) flop, and the pipe they run on
-_EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0)
+_EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0, 6.0, 3.0)
 
 
 def _wino_ok(srcs, weight, out_mode, W):
@@ -417,8 +424,10 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     out2_grouped8: a zero-bordered group-major buffer [B,Cout/8,H+3,W+3,8] that receives a second copy of the output
     (what the DCNv2 kernel gathers 8-channel groups from); "nhwc" mode on the direct kernel only.
     algo: None (auto), "direct", "winograd", "winograd4", "split" (fp32-accurate on the bf16 matrix pipe: three exact bf16
-    pieces per operand, six MFMAs per product sum, csrc/conv3x3_split.hip), "bf16" (one rounded piece: a bf16 convolution
-    with fp32 accumulation).  Auto: the split kernel wherever it applies (any map size / mode, channels % 16 == 0).
+    pieces per operand, six MFMAs per product sum, csrc/conv3x3_split.hip), "split16" (fp32-accurate on the f16 matrix pipe:
+    two round-to-nearest f16 pieces per activation, per-tensor-scaled weights, THREE MFMAs per product sum; |x| < 65520),
+    "bf16" (one rounded piece: a bf16 convolution with fp32 accumulation).  Auto: the split kernel wherever it applies (any
+    map size / mode, channels % 16 == 0), f16 x 2 flavour unless $C2M_CONV_SPLIT16=0.
     $C2M_CONV_SPLIT=1 restricts it to calls with fast=True (the decoder; the extractor towers that feed the index search
     then stay on the fp32-MFMA kernels), $C2M_CONV_SPLIT=0 restores the round-2 choice everywhere: Winograd F(4,3) with
     fast=True / F(2,3) where the shapes allow, else direct."""
@@ -431,7 +440,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         reduced = bf16_autocast()
         if (out2_grouped8 is None and (_split_ok(srcs, weight, fast) or (reduced and _split_ok(srcs, weight, True))) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
                 and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
-            wino = 4 if reduced else 3
+            wino = 4 if reduced else 6 if _SPLIT16 else 3
         else:
             wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
@@ -442,7 +451,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         wino = 0
     wr = _wcache.get(weight, pad_cin_to=Cin if weight.shape[1] < Cin else None, wino=wino)
     d = _lib.Conv3x3Desc()
-    d.algo = wino
+    d.algo = _DESC_ALGO[wino]
     d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, Cout, len(srcs)
     for k, s in enumerate(srcs):
         if tuple(s.shape[2:]) != (H, W) or s.shape[0] != B:
@@ -473,7 +482,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         o = _nhwc_src(out, "out")
         d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
     elif out_mode == "nhwc_pool2":
-        if wino not in (1, 3, 4) or H % 2 != 0 or W % 2 != 0:
+        if wino not in (1, 3, 4, 6) or H % 2 != 0 or W % 2 != 0:
             raise _lib.C2MError("conv3x3: the pooled epilogue needs the Winograd F(2,3) or the split-bf16 kernel and even H, W")
         out = empty_nhwc(B, Cout, H // 2, W // 2, dev)
         d.out_mode = 4
@@ -686,8 +695,9 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         raise _lib.C2MError("abs_sum must be a float64 GPU tensor with 256 slots (C2M_ABS_SUM_SLOTS)")
     split = (Cout // 64) * 64
     slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
-    use_split = algo in ("split", "bf16") or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
-    split_id = 4 if (algo == "bf16" or (algo is None and bf16_autocast())) else 3
+    use_split = algo in ("split", "bf16", "split16") or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
+    split_id = (4 if (algo == "bf16" or (algo is None and bf16_autocast())) else
+                6 if (algo == "split16" or (algo is None and _SPLIT16)) else 3)
     fam = []
     for (c0, c1) in slices:
         # split-bf16 kernel (any shape); else 64-channel-tileable slices on whole 32-pixel tiles take the Winograd F(2,3)
@@ -697,7 +707,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
         fam.append(wino)
         wr = _wcache.get(weight, rows=(c0, c1), wino=wino)
         d = _lib.Conv3x3Desc()
-        d.algo = wino
+        d.algo = _DESC_ALGO[wino]
         d.B, d.H, d.W, d.Cin, d.Cout, d.nsrc = B, H, W, Cin, c1 - c0, len(srcs)
         for k, s in enumerate(srcs):
             d.src[k] = _nhwc_src(s, f"src{k}")

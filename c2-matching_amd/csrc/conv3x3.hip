@@ -1501,7 +1501,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     return C2M_ERR_INVALID_ARG;
   const bool wino4 = d->algo == C2M_CONV_WINOGRAD_F43X;
   const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X || wino4;   // both: 16-channel chunks, 64-cout blocks
-  const bool splitk = d->algo == C2M_CONV_SPLIT_BF16X3 || d->algo == C2M_CONV_BF16;   // 16-channel chunks, any shape
+  const bool splitk = d->algo == C2M_CONV_SPLIT_BF16X3 || d->algo == C2M_CONV_BF16 || d->algo == C2M_CONV_SPLIT_F16X2;   // 16-channel chunks, any shape
   if (d->algo != 0 && !wino && !splitk) return C2M_ERR_INVALID_ARG;
   if (splitk && (d->out2 || (d->out_mode == 4 && (d->H % 2 != 0 || d->W % 2 != 0 || d->res1 || d->res2)))) return C2M_ERR_UNSUPPORTED;
   if (wino && ((d->out_mode != 0 && d->out_mode != 3 && d->out_mode != 4) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
@@ -1572,7 +1572,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   }
   if (splitk) {
     ProfileScope prof(C2M_KERNEL_CONV3X3_SPLIT, as_stream(stream));
-    return conv::launch_split(as_stream(stream), p, d->algo == C2M_CONV_BF16 ? 1 : 3);
+    return conv::launch_split(as_stream(stream), p, d->algo == C2M_CONV_BF16 ? 1 : (d->algo == C2M_CONV_SPLIT_F16X2 ? 2 : 3));
   }
   // tiles per workgroup: long streams amortise the set-up and the first DMA wait, but the launch is only as fast as its
   // last round of 512 resident workgroups (2 per CU; the F(4,3) kernel: 256, 1 per CU): take the tpw <= 10 with the fewest

@@ -39,6 +39,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "c2m_common.h"
@@ -66,13 +67,32 @@ constexpr int HALFB = NRAW * 256 + 64;          // one (plane, k half) slab: 384
                                                 // of the LDS-active cycles)
 static_assert(HALFB % 128 == 64 && HALFB % 16 == 0, "bank phase of the second k half");
 
-template <int NP> struct Products;
-template <> struct Products<1> { static constexpr int N = 1; static constexpr int W[1] = {0}; static constexpr int X[1] = {0}; };
-template <> struct Products<3> {
-  static constexpr int N = 6;   // smallest terms first, the leading product last
+// Flavour FL of the arithmetic: NPX input planes, NPW weight images, N piece products (weight image W[g] x input plane X[g]).
+//   FL = 3  bf16 x 3: three exact bf16 pieces of both operands, six products (full fp32 range)
+//   FL = 1  bf16: one round-to-nearest piece, one product (BASELINE configs[4])
+//   FL = 2  f16 x 2: x = x0 + 2^-11 x1' + e,  x0 = rne_f16(x), x1' = rne_f16(2^11 (x - x0))   (|e| <= max(2^-22 |x|, 2^-36))
+//           and, with the per-tensor power of two S that puts max |w| into [2^14, 2^15):
+//           wA = rne_f16(S w), w1 = rne_f16(S w - wA), wB = 2^-11 wA (a third IMAGE instead of a second accumulator);
+//           S w.x ~= wA.x0 + w1.x0 + wB.x1'   (dropped: w1 (x - x0) <= 2^-22 |w||x|);  the epilogue multiplies by 1/S.
+//           Three products instead of six.  Domain: |x| < 65520 (beyond: NaN, never a silently wrong number).
+template <int FL> struct Flavour;
+template <> struct Flavour<1> {
+  static constexpr int NPX = 1, NPW = 1, N = 1; static constexpr bool F16 = false;
+  static constexpr int W[1] = {0}; static constexpr int X[1] = {0};
+};
+template <> struct Flavour<3> {
+  static constexpr int NPX = 3, NPW = 3, N = 6; static constexpr bool F16 = false;   // smallest terms first, the leading product last
   static constexpr int W[6] = {2, 0, 1, 1, 0, 0};
   static constexpr int X[6] = {0, 2, 1, 0, 1, 0};
 };
+template <> struct Flavour<2> {
+  static constexpr int NPX = 2, NPW = 3, N = 3; static constexpr bool F16 = true;    // images: 0 = wA, 1 = w1, 2 = wB
+  static constexpr int W[3] = {2, 1, 0};
+  static constexpr int X[3] = {1, 0, 0};
+};
+constexpr float F16_LO_SCALE = 2048.0f;   // 2^11: the low piece of an f16 x 2 operand is stored times this
+constexpr int npw_of(int fl) { return fl == 1 ? 1 : 3; }
+constexpr int npx_of(int fl) { return fl == 2 ? 2 : fl; }
 
 // exact three-way split of four fp32 values into bf16 pairs (truncation: the residuals are exact in fp32)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -87,6 +107,35 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& p0, u32x2& p1, u32x
   p0 = u32x2{__builtin_amdgcn_perm(vb[1], vb[0], 0x07060302u), __builtin_amdgcn_perm(vb[3], vb[2], 0x07060302u)};
   p1 = u32x2{__builtin_amdgcn_perm(rb[1], rb[0], 0x07060302u), __builtin_amdgcn_perm(rb[3], rb[2], 0x07060302u)};
   p2 = u32x2{__builtin_amdgcn_perm(tb[1], tb[0], 0x07060302u), __builtin_amdgcn_perm(tb[3], tb[2], 0x07060302u)};
+}
+
+// exact two-way f16 split of four fp32 values: p0 = rne_f16(v), p1 = rne_f16(2^11 (v - p0))
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2_f16(const f32x4 v, u32x2& p0, u32x2& p1) {
+  const f16x4 h0 = __builtin_convertvector(v, f16x4);
+  const f32x4 r = (v - __builtin_convertvector(h0, f32x4)) * F16_LO_SCALE;
+  const f16x4 h1 = __builtin_convertvector(r, f16x4);
+  p0 = __builtin_bit_cast(u32x2, h0);
+  p1 = __builtin_bit_cast(u32x2, h1);
+}
+
+// power of two S with S * wmax in [2^14, 2^15) (1 for wmax = 0 / non-finite)
+__device__ __forceinline__ float f16_weight_scale(float wmax) {
+  if (!(wmax > 0.0f) || wmax > 3.0e38f) return 1.0f;
+  int e;
+  (void)frexpf(wmax, &e);          // wmax = m 2^e, m in [0.5, 1)
+  e = 15 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.0f, e);
+}
+__device__ __forceinline__ unsigned short f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ unsigned short f16_piece(float w, int pl, float S) {
+  const float v = w * S;                       // exact (power of two)
+  const _Float16 a = (_Float16)v;
+  if (pl == 0) return __builtin_bit_cast(unsigned short, a);
+  if (pl == 1) return f16_bits(v - (float)a);
+  return f16_bits((float)a * (1.0f / F16_LO_SCALE));
 }
 
 __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) {
@@ -105,9 +154,16 @@ __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) 
 // value = piece `plane` of W[cb*32*MT + mt*32 + row][chunk*16 + 8*half + e][dy][dx] (0 beyond Cout)
 // dgrad != 0: images of the DATA-GRADIENT convolution instead (Cin/Cout = its input/output channels = the forward's
 // Cout/Cin): value = piece of w[ci][co][2-dy][2-dx] with w the forward weight [Cin here][Cout here][3][3]
-__global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float* __restrict__ w, int Cin, int Cout, int NP, int MT,
+// fl = 2: the image is followed by a 256-byte tail {float 1/S, uint bits of max |w| (written by weight_absmax_kernel)}
+__global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float* __restrict__ w, int Cin, int Cout, int fl, int MT,
                                                                       long long total, unsigned short* __restrict__ wr, int dgrad) {
+  const int NP = npw_of(fl);
   const long long e0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  float S = 1.0f;
+  if (fl == 2) {
+    S = f16_weight_scale(__builtin_bit_cast(float, reinterpret_cast<const unsigned*>(wr + total)[1]));
+    if (e0 == 0) reinterpret_cast<float*>(wr + total)[0] = 1.0f / S;
+  }
   if (e0 >= total) return;
   const int e = (int)(e0 & 7), row = (int)((e0 >> 3) & 31), half = (int)((e0 >> 8) & 1);
   long long r = e0 >> 9;
@@ -121,7 +177,17 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float
   const int co = (cb * MT + mt) * 32 + row, ci = chunk * KC + 8 * half + e;
   float v = 0.0f;
   if (co < Cout) v = dgrad ? w[((size_t)ci * Cout + co) * 9 + (2 - dy) * 3 + (2 - dx)] : w[((size_t)co * Cin + ci) * 9 + dy * 3 + dx];
-  wr[e0] = bf16_piece(v, pl, NP == 1);
+  wr[e0] = fl == 2 ? f16_piece(v, pl, S) : bf16_piece(v, pl, fl == 1);
+}
+
+// max |w| as uint bits (monotonic for non-negative floats; NaN -> large) into slot[1], zeroed by the caller
+__global__ void __launch_bounds__(256) weight_absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ slot) {
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    m = max(m, __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + 1, m);
 }
 
 // compile-time loop and LDS instructions with immediate offsets (hand-placed: hipcc re-uses operand registers and then
@@ -166,13 +232,14 @@ __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
 
 // ABL > 0: timing-only ablations (WRONG results; $C2M_SPLIT_ABL): 1 no weight DMA after the prologue, 2 no halo DMA, 3 no
 // split of the raw tile, 4 no unit-end waits / barriers, 5 no MFMAs, 6 no operand reads, 7 MFMAs + barriers only, 8 MFMAs only
-template <int NP, int MT, int MODE, int ABL = 0>
+template <int FL, int MT, int MODE, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   constexpr int NT = 2;
   constexpr int MW = 32 * MT;
-  using PR = Products<NP>;
-  constexpr int PLB = NP * 2 * HALFB;           // bytes of one plane buffer
-  constexpr int WTAP = NP * MT * 1024;          // one tap's weight image: [plane][mt][half][32 rows][16 B]
+  using PR = Flavour<FL>;
+  constexpr int NPX = PR::NPX, NPW = PR::NPW;
+  constexpr int PLB = NPX * 2 * HALFB;          // bytes of one plane buffer
+  constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
   constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
   constexpr int NWI = WUNIT / 1024;             // LDS-DMA instructions per unit
   constexpr int NW_W = (NWI + 3) / 4;           // per wave (the last wave pads with dummies: uniform vmcnt counts)
@@ -279,8 +346,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;   // + r * 1024 + plane * 2*HALFB
   u32x2 cq[3];
   auto conv_split = [&](const f32x4 v) __attribute__((always_inline)) {
-    if constexpr (NP == 3) {
+    if constexpr (FL == 3) {
       split3(v, cq[0], cq[1], cq[2]);
+    } else if constexpr (FL == 2) {
+      split2_f16(v, cq[0], cq[1]);
     } else {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 h;
@@ -292,18 +361,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   auto conv_store = [&](auto rr) __attribute__((always_inline)) {
     constexpr int R = decltype(rr)::value;
     lds_write64<R * 1024>(cdst, cq[0]);
-    if constexpr (NP == 3) {
-      lds_write64<R * 1024 + 2 * HALFB>(cdst, cq[1]);
-      lds_write64<R * 1024 + 4 * HALFB>(cdst, cq[2]);
-    }
+    if constexpr (NPX >= 2) lds_write64<R * 1024 + 2 * HALFB>(cdst, cq[1]);
+    if constexpr (NPX >= 3) lds_write64<R * 1024 + 4 * HALFB>(cdst, cq[2]);
   };
 
   // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, plane pl, channel tile mt;
   //                B = pixel (row 2wv + nt + dy, column j + dx) of the halo tile, k half hi, plane pl
   const unsigned abase = w_base + hi * 512 + j * 16;
   const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
-  bf16x8 A[2][NP][MT], Bq[2][NP][NT];   // two operand sets: tap (dy, dx) multiplies set (dy + dx) & 1
-  constexpr int NLB = NP * NT, NLA = NP * MT;
+  bf16x8 A[2][NPW][MT], Bq[2][NPX][NT];   // two operand sets: tap (dy, dx) multiplies set (dy + dx) & 1
+  constexpr int NLB = NPX * NT, NLA = NPW * MT;
   auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {   // aslot = abase + ring slot offset
     constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
     lds_read128<DX * WTAP + K * 1024>(A[SET][K / MT][K % MT], aslot);
@@ -314,6 +381,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   };
 
   const int co_lane = cb * MW + 4 * hi;
+  // f16 x 2: 1/S of the weight images (the float behind the last cout block's image)
+  float w_sinv = 1.0f;
+  if constexpr (FL == 2) w_sinv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wr) + (size_t)gridDim.y * UT * WUNIT);
   if (tid < MW) {
     const int co = cb * MW + tid;
     *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
@@ -343,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // the barrier that publishes the unit's weights), the unit's first tap also issues the LDS-DMA pieces of the NEXT unit's
   // weights, one per group.  Unit end: own LDS ops / DMAs done, barrier (publishes W(u+1), frees the planes / ring slot).
   constexpr int NG = PR::N;
-  constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NLA + NLB);   // operand reads per group
+  constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NG == 3 ? (NLA + NLB + 1) / 2 : NLA + NLB);   // operand reads per group
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       const bool more_in = ABL != 2 && gc + 1 < G;
@@ -407,7 +477,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][PR::W[g]][mt], Bq[set][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
+                  if constexpr (PR::F16)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[set][PR::W[g]][mt]),
+                                                                         __builtin_bit_cast(f16x8, Bq[set][PR::X[g]][nt]), acc[mt][nt], 0, 0, 0);
+                  else
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][PR::W[g]][mt], Bq[set][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -435,7 +509,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mt][nt][4 * qd + e] += bv[e];
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (FL == 2) acc[mt][nt][4 * qd + e] = acc[mt][nt][4 * qd + e] * w_sinv + bv[e];   // (power of two: exact)
+            else acc[mt][nt][4 * qd + e] += bv[e];
+          }
       }
     if constexpr (MODE == 3) {
       float asum = 0.0f;
@@ -573,16 +650,28 @@ using namespace c2m;
 namespace c2m {
 namespace conv {
 
-size_t split_relayout_bytes(int Cin, int Cout, int np) {
-  if (Cin <= 0 || Cout <= 0 || Cin % split::KC != 0 || (np != 1 && np != 3)) return 0;
+// np = flavour: 3 bf16 x 3, 1 bf16, 2 f16 x 2 (image + 256-byte tail holding 1/S)
+static size_t split_image_bytes(int Cin, int Cout, int np) {
+  if (Cin <= 0 || Cout <= 0 || Cin % split::KC != 0 || (np != 1 && np != 2 && np != 3)) return 0;
   const int MT = Cout <= 32 ? 1 : 2, ncb = (Cout + 32 * MT - 1) / (32 * MT);
-  return (size_t)ncb * (Cin / split::KC) * 9 * np * MT * 1024;
+  return (size_t)ncb * (Cin / split::KC) * 9 * split::npw_of(np) * MT * 1024;
+}
+
+size_t split_relayout_bytes(int Cin, int Cout, int np) {
+  const size_t b = split_image_bytes(Cin, Cout, np);
+  return b == 0 ? 0 : b + (np == 2 ? 256 : 0);
 }
 
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad) {
-  const size_t bytes = split_relayout_bytes(Cin, Cout, np);
+  const size_t bytes = split_image_bytes(Cin, Cout, np);
   if (bytes == 0) return C2M_ERR_UNSUPPORTED;
   const long long total = (long long)(bytes / 2);
+  if (np == 2) {   // per-tensor scale: max |w| -> tail of the image
+    const long long n = (long long)Cin * Cout * 9;
+    (void)hipMemsetAsync(reinterpret_cast<char*>(wr) + bytes, 0, 256, st);
+    hipLaunchKernelGGL(split::weight_absmax_kernel, dim3((unsigned)std::min<long long>(64, (n + 4095) / 4096)), dim3(256), 0, st, weight, n,
+                       reinterpret_cast<unsigned*>(reinterpret_cast<char*>(wr) + bytes));
+  }
   hipLaunchKernelGGL(split::conv3x3_relayout_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, Cin,
                      Cout, np, Cout <= 32 ? 1 : 2, total, reinterpret_cast<unsigned short*>(wr), dgrad);
   return check_launch();
@@ -590,7 +679,7 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
-  constexpr size_t ldsb = (size_t)(NP * 2 * split::HALFB) + 2 * (size_t)(3 * NP * MT * 1024) + 1024 + 256;   // planes, weight ring x2, dummy, bias
+  constexpr size_t ldsb = (size_t)(split::npx_of(NP) * 2 * split::HALFB) + 2 * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 + 256;   // planes, weight ring x2, dummy, bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {
@@ -651,6 +740,7 @@ int launch_split(hipStream_t st, Params p, int np) {
   dim3 grid((unsigned)((ntile + tpw - 1) / tpw), ncb);
   int rc;
   if (np == 3) rc = MT == 2 ? launch_split_mode<3, 2>(st, p, grid) : launch_split_mode<3, 1>(st, p, grid);
+  else if (np == 2) rc = MT == 2 ? launch_split_mode<2, 2>(st, p, grid) : launch_split_mode<2, 1>(st, p, grid);
   else rc = MT == 2 ? launch_split_mode<1, 2>(st, p, grid) : launch_split_mode<1, 1>(st, p, grid);
   if (rc != C2M_OK) return rc;
   return check_launch();

@@ -194,7 +194,8 @@ typedef struct c2m_conv_src {
   long long img_pitch;   /* floats between samples */
 } c2m_conv_src;
 
-enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2, C2M_CONV_SPLIT_BF16X3 = 3, C2M_CONV_BF16 = 4 };
+enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2, C2M_CONV_SPLIT_BF16X3 = 3, C2M_CONV_BF16 = 4,
+       C2M_CONV_SPLIT_F16X2 = 5 };
 enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3, C2M_OUT_NHWC_MAXPOOL2 = 4 };
 
 typedef struct c2m_conv3x3_desc {
@@ -232,7 +233,15 @@ typedef struct c2m_conv3x3_desc {
                               the fp32-MFMA time, error below an fp32 fmaf chain; any out_mode (C2M_OUT_NHWC_MAXPOOL2 included),
                               any H, W, channels % 16 == 0, no out2; `wr` from c2m_conv3x3_relayout_split_f32(pieces = 3).
                               C2M_CONV_BF16 (4): the same kernel with one round-to-nearest bf16 piece per operand -- a plain bf16
-                              convolution with fp32 accumulation (bf16 inference, BASELINE configs[4]); pieces = 1 */
+                              convolution with fp32 accumulation (bf16 inference, BASELINE configs[4]); pieces = 1.
+                              C2M_CONV_SPLIT_F16X2 (5): fp32 result on the F16 matrix pipe with THREE products: activations split
+                              x = x0 + 2^-11 x1' (round-to-nearest halves: |x - x0 - 2^-11 x1'| <= max(2^-22 |x|, 2^-36)), weights scaled
+                              by the per-tensor power of two S that puts max |w| into [2^14, 2^15) and split the same way;
+                              S w.x = wA.x0 + w1.x0 + (2^-11 wA).x1' (dropped: <= 2^-22 |w||x|), one accumulator, times 1/S in the
+                              epilogue.  Error of the same class as the fp32 accumulation chain itself (tests/test_conv_gpu.py
+                              holds it to the tolerance of the other fp32 kernels).  Domain: |x| < 65520 -- larger inputs give NaN
+                              (never a silently wrong number); for such data use C2M_CONV_SPLIT_BF16X3 (full fp32 range).
+                              pieces = 2 (the image carries 1/S behind it) */
   int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
   int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
                               head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
@@ -249,7 +258,7 @@ size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout);   /* 0 if unsupported
 int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout);  /* 0 if unsupported (Cin % 16, Cout % 64) */
 int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
-size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3 or 1; 0 if unsupported (Cin % 16) */
+size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3, 1 or 2 (f16 x 2); 0 if unsupported (Cin % 16) */
 int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
 

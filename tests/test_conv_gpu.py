@@ -295,9 +295,11 @@ def test_conv3x3_winograd_matches_fp64_and_direct(ops, dev, case):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# split-bf16 kernel (csrc/conv3x3_split.hip): fp32 operands split exactly into three bf16 pieces, six piece products per
-# product sum on the bf16 matrix pipe.  Held to the DIRECT kernel's tolerance (1e-5 * scale against float64).
+# split kernel (csrc/conv3x3_split.hip).  "split": fp32 operands split exactly into three bf16 pieces, six piece products per
+# product sum on the bf16 matrix pipe.  "split16": two round-to-nearest f16 pieces per activation, per-tensor-scaled weights,
+# three products on the f16 matrix pipe.  Both held to the DIRECT kernel's tolerance (1e-5 * scale against float64).
 # ---------------------------------------------------------------------------------------------------------------------
+SPLIT_ALGOS = ("split", "split16")
 SPLIT_CASES = [c for c in CASES if c[2] % 4 == 0] + WINO_CASES + [   # (Cout = 3: planar output only, see the modes test)
     (1, [16], 64, 8, 32, 0, 0),          # one chunk: prologue only, no steady state
     (1, [32], 64, 3, 5, 1, 0),           # map smaller than a tile
@@ -306,22 +308,24 @@ SPLIT_CASES = [c for c in CASES if c[2] % 4 == 0] + WINO_CASES + [   # (Cout = 3
 ]
 
 
+@pytest.mark.parametrize("algo", SPLIT_ALGOS)
 @pytest.mark.parametrize("case", SPLIT_CASES)
-def test_conv3x3_split_matches_fp64_conv2d(ops, dev, case):
+def test_conv3x3_split_matches_fp64_conv2d(ops, dev, case, algo):
     B, cins, Cout, H, W, act, nres = case
     xs = [_cl(_rand((B, c, H, W), dev, 210 + k)) for k, c in enumerate(cins)]
     w = _rand((Cout, sum(cins), 3, 3), dev, 220, 1.0 / np.sqrt(9 * sum(cins)))
     b = _rand((Cout,), dev, 221)
     res = [_cl(_rand((B, Cout, H, W), dev, 230 + k)) for k in range(nres)]
     kw = dict(act=act, slope=0.1, res1=res[0] if nres > 0 else None, res2=res[1] if nres > 1 else None)
-    got = ops.conv3x3(xs, w, b, algo="split", **kw)
+    got = ops.conv3x3(xs, w, b, algo=algo, **kw)
     want = _ref(xs, w, b, act, 0.1, res)
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     scale = max(1.0, float(want.abs().max()))
     err = float((got.double() - want).abs().max())
     assert err < 1e-5 * scale, err
-    auto = ops.conv3x3(xs, w, b, fast=True, **kw)          # the automatic choice with fast=True is this kernel
-    assert torch.equal(auto, got)
+    if algo == ("split16" if ops._SPLIT16 else "split"):   # the automatic choice is this kernel
+        auto = ops.conv3x3(xs, w, b, fast=True, **kw)
+        assert torch.equal(auto, got)
 
 
 def test_conv3x3_split_is_at_least_as_accurate_as_the_fp32_mfma_kernels(ops, dev):
@@ -331,34 +335,76 @@ def test_conv3x3_split_is_at_least_as_accurate_as_the_fp32_mfma_kernels(ops, dev
     x = _cl(_rand((1, 256, 24, 64), dev, 300))
     w, b = _rand((256, 256, 3, 3), dev, 301, 1.0 / 48.0), _rand((256,), dev, 302)
     want = _ref([x], w, b, 0, 0.0, [])
-    errs = {a: float((ops.conv3x3(x, w, b, algo=a).double() - want).abs().max()) for a in ("direct", "winograd", "split")}
+    errs = {a: float((ops.conv3x3(x, w, b, algo=a).double() - want).abs().max()) for a in ("direct", "winograd", "split", "split16")}
     assert errs["split"] <= 1.5 * errs["direct"] + 1e-7, errs
+    assert errs["split16"] <= 1.5 * errs["direct"] + 1e-7, errs
+    # ... and in the root-mean-square sense too
+    rms = {a: float((ops.conv3x3(x, w, b, algo=a).double() - want).pow(2).mean().sqrt()) for a in ("direct", "split", "split16")}
+    assert rms["split"] <= 1.5 * rms["direct"] and rms["split16"] <= 1.5 * rms["direct"], rms
 
 
-def test_conv3x3_split_output_modes(ops, dev):
+@pytest.mark.parametrize("xs_,ws_", [(1e-3, 1.0), (1e3, 1.0), (1.0, 1e-6), (1.0, 1e5), (3e-3, 2e-4), (250.0, 37.0)])
+def test_conv3x3_split16_scales(ops, dev, xs_, ws_):
+    """f16 x 2 flavour away from unit scale: activations of magnitude 1e-3 ... 1e3 (the low piece is stored times 2^11: no
+    fp16 underflow down to 2^-36 absolute) and weights of any magnitude (per-tensor power-of-two scale) keep the RELATIVE
+    accuracy of the unit-scale case."""
+    x = _cl(_rand((1, 64, 16, 40), dev, 330)) * xs_
+    w, b = _rand((64, 64, 3, 3), dev, 331, 1.0 / 24.0) * ws_, _rand((64,), dev, 332) * (xs_ * ws_)
+    want = _ref([x], w, b, 0, 0.0, [])
+    scale = float(want.abs().max())
+    e16 = float((ops.conv3x3(x, w, b, algo="split16").double() - want).abs().max())
+    ed = float((ops.conv3x3(x, w, b, algo="direct").double() - want).abs().max())
+    assert e16 < 1e-5 * scale and e16 <= 1.5 * ed + 1e-7 * scale, (e16, ed, scale)
+
+
+def test_conv3x3_split16_domain(ops, dev):
+    """Outside |x| < 65520 the f16 x 2 flavour returns NaN where the oversized value is read (never a finite wrong number);
+    the bf16 x 3 flavour covers the whole fp32 range.  Zero weights (the zero-initialised DCN heads): exactly the bias.
+    A mixed-magnitude activation map (1e-6 ... 1e4 in one tensor) keeps the accuracy relative to the OUTPUT scale."""
+    x = _cl(_rand((1, 32, 8, 32), dev, 333))
+    w, b = _rand((32, 32, 3, 3), dev, 334, 0.06), _rand((32,), dev, 335)
+    xb = x.clone()
+    xb[0, 5, 4, 7] = 1.0e5
+    got = ops.conv3x3(xb, w, b, algo="split16")
+    assert bool(torch.isnan(got[0, :, 3:6, 6:9]).all()) and bool(torch.isfinite(got[0, :, :, 10:]).all())
+    ok = ops.conv3x3(xb, w, b, algo="split")
+    want = _ref([xb], w, b, 0, 0.0, [])
+    assert float((ok.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    z = ops.conv3x3(x, torch.zeros_like(w), b, algo="split16")
+    assert torch.equal(z, b.view(1, -1, 1, 1).expand_as(z))
+    mag = 10.0 ** (_rand((1, 32, 8, 32), dev, 336) * 2.5 - 1.0).clamp(-6.0, 3.5)   # 1e-6 ... 3e3 (x itself reaches ~4)
+    xm = _cl(x * mag)
+    want = _ref([xm], w, b, 0, 0.0, [])
+    e16 = float((ops.conv3x3(xm, w, b, algo="split16").double() - want).abs().max())
+    ed = float((ops.conv3x3(xm, w, b, algo="direct").double() - want).abs().max())
+    assert e16 < 1e-5 * float(want.abs().max()) and e16 <= 1.5 * ed + 1e-7 * float(want.abs().max()), (e16, ed)
+
+
+@pytest.mark.parametrize("algo", SPLIT_ALGOS)
+def test_conv3x3_split_output_modes(ops, dev, algo):
     """PixelShuffle(2), planar NCHW, ReLU + MaxPool2d(2, 2), a channel-slice source and a strided (bordered) destination."""
     x = _cl(_rand((2, 64, 24, 40), dev, 304))
     w, b = _rand((256, 64, 3, 3), dev, 305, 0.05), _rand((256,), dev, 306)
-    got = ops.conv3x3(x, w, b, act=ops.ACT_LRELU, slope=0.1, out_mode="pixel_shuffle", algo="split")
+    got = ops.conv3x3(x, w, b, act=ops.ACT_LRELU, slope=0.1, out_mode="pixel_shuffle", algo=algo)
     want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double(), padding=1), 2), 0.1)
     assert tuple(got.shape) == (2, 64, 48, 80)
     assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     w3, b3 = _rand((3, 64, 3, 3), dev, 307, 0.05), _rand((3,), dev, 308)
-    got = ops.conv3x3(x, w3, b3, out_mode="nchw", algo="split")
+    got = ops.conv3x3(x, w3, b3, out_mode="nchw", algo=algo)
     want = F.conv2d(x.double(), w3.double(), b3.double(), padding=1)
     assert got.is_contiguous() and float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     for (B, C, Co, H, W) in ((2, 64, 64, 12, 64), (1, 128, 128, 22, 90), (1, 64, 32, 8, 6)):
         xp = _cl(_rand((B, C, H, W), dev, 310))
         wp, bp = _rand((Co, C, 3, 3), dev, 311, 1.0 / np.sqrt(9 * C)), _rand((Co,), dev, 312)
-        got = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, out_mode="nhwc_pool2", algo="split")
-        plain = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, algo="split")
+        got = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, out_mode="nhwc_pool2", algo=algo)
+        plain = ops.conv3x3(xp, wp, bp, act=ops.ACT_RELU, algo=algo)
         assert got.shape == (B, Co, H // 2, W // 2) and torch.equal(got, F.max_pool2d(plain, 2, 2))
     big = _cl(_rand((2, 128, 24, 40), dev, 313))
     xs = big[:, 32:96]
     w2, b2 = _rand((64, 64, 3, 3), dev, 314, 0.05), _rand((64,), dev, 315)
     bo = ops._bordered_empty(2, 64, 24, 40, dev)
     view = bo.interior()
-    ops.conv3x3(xs, w2, b2, out=view, algo="split")
+    ops.conv3x3(xs, w2, b2, out=view, algo=algo)
     want = _ref([xs], w2, b2, 0, 0.1, [])
     assert float((view.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, :, 41:].abs().max()) == 0
@@ -379,7 +425,8 @@ def test_conv3x3_bf16_single_piece_is_a_bf16_convolution(ops, dev):
     assert 1e-4 < rel < 1e-2, rel
 
 
-def test_dcn_head_on_the_split_kernel(ops, dev):
+@pytest.mark.parametrize("algo", SPLIT_ALGOS)
+def test_dcn_head_on_the_split_kernel(ops, dev, algo):
     """DCN offset/mask head epilogue of the split kernel (192 + 24 channels): same check as the fp32-MFMA kernels'."""
     import c2m_oracle as oracle
     import synth
@@ -392,7 +439,7 @@ def test_dcn_head_on_the_split_kernel(ops, dev):
         idx = (synth.uniform((B, hp, wp), 363, 0.0, 1.0).astype(np.float64) * (hp * wp)).astype(np.int64) % (hp * wp)
         flow = ops.index_to_flow(torch.from_numpy(idx).to(dev))
         abs_sum = torch.zeros(256, dtype=torch.float64, device=dev)
-        off, msk = ops.conv3x3_dcn_head(feat, wt, bs, dg, flow, s, abs_sum, algo="split")
+        off, msk = ops.conv3x3_dcn_head(feat, wt, bs, dg, flow, s, abs_sum, algo=algo)
         raw = F.conv2d(feat.double(), wt.double(), bs.double(), padding=1)
         o1, o2, m = torch.chunk(raw, 3, dim=1)
         want_off = torch.cat((o1, o2), 1)
@@ -410,7 +457,7 @@ def test_weight_cache_refresh_follows_data_writes(ops, dev):
     call) rebuilds the cached weight images from the tensor's current contents."""
     x = _cl(_rand((1, 32, 8, 8), dev, 350))
     w = torch.nn.Parameter(_rand((32, 32, 3, 3), dev, 351, 0.1))
-    for algo in ("direct", "split"):
+    for algo in ("direct", "split", "split16"):
         a = ops.conv3x3(x, w, algo=algo)
         v0 = w._version
         w.data.mul_(2.0)
