@@ -72,7 +72,7 @@ static_assert(HALFB % 128 == 64 && HALFB % 16 == 0, "bank phase of the second k 
 //   FL = 1  bf16: one round-to-nearest piece, one product (BASELINE configs[4])
 //   FL = 2  f16 x 2: x = x0 + 2^-11 x1' + e,  x0 = rne_f16(x), x1' = rne_f16(2^11 (x - x0))   (|e| <= max(2^-22 |x|, 2^-36))
 //           and, with the per-tensor power of two S that puts max |w| into [2^14, 2^15):
-//           wA = rne_f16(S w), w1 = rne_f16(S w - wA), wB = 2^-11 wA (a third IMAGE instead of a second accumulator);
+//           wA = rne_f16(S w), w1 = rne_f16(S w - wA), wB = 2^-11 wA (a third A OPERAND instead of a second accumulator);
 //           S w.x ~= wA.x0 + w1.x0 + wB.x1'   (dropped: w1 (x - x0) <= 2^-22 |w||x|);  the epilogue multiplies by 1/S.
 //           Three products instead of six.  Domain: |x| < 65520 (beyond: NaN, never a silently wrong number).
 template <int FL> struct Flavour;
@@ -86,12 +86,12 @@ template <> struct Flavour<3> {
   static constexpr int X[6] = {0, 2, 1, 0, 1, 0};
 };
 template <> struct Flavour<2> {
-  static constexpr int NPX = 2, NPW = 3, N = 3; static constexpr bool F16 = true;    // images: 0 = wA, 1 = w1, 2 = wB
-  static constexpr int W[3] = {2, 1, 0};
-  static constexpr int X[3] = {1, 0, 0};
+  static constexpr int NPX = 2, NPW = 2, N = 3; static constexpr bool F16 = true;    // images: 0 = wA, 1 = w1; "2" = wB = 2^-11 wA,
+  static constexpr int W[3] = {1, 2, 0};                                              // derived in registers (4 v_pk_mul_f16 per operand)
+  static constexpr int X[3] = {0, 1, 0};
 };
 constexpr float F16_LO_SCALE = 2048.0f;   // 2^11: the low piece of an f16 x 2 operand is stored times this
-constexpr int npw_of(int fl) { return fl == 1 ? 1 : 3; }
+constexpr int npw_of(int fl) { return fl == 1 ? 1 : fl; }
 constexpr int npx_of(int fl) { return fl == 2 ? 2 : fl; }
 
 // exact three-way split of four fp32 values into bf16 pairs (truncation: the residuals are exact in fp32)
@@ -134,8 +134,7 @@ __device__ __forceinline__ unsigned short f16_piece(float w, int pl, float S) {
   const float v = w * S;                       // exact (power of two)
   const _Float16 a = (_Float16)v;
   if (pl == 0) return __builtin_bit_cast(unsigned short, a);
-  if (pl == 1) return f16_bits(v - (float)a);
-  return f16_bits((float)a * (1.0f / F16_LO_SCALE));
+  return f16_bits(v - (float)a);
 }
 
 __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) {
@@ -230,8 +229,9 @@ __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
   asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
 }
 
-// ABL > 0: timing-only ablations (WRONG results; $C2M_SPLIT_ABL): 1 no weight DMA after the prologue, 2 no halo DMA, 3 no
-// split of the raw tile, 4 no unit-end waits / barriers, 5 no MFMAs, 6 no operand reads, 7 MFMAs + barriers only, 8 MFMAs only
+// ABL > 0: timing-only ablations (WRONG results; $C2M_SPLIT_ABL), a bit mask: 1 no weight DMA after the prologue, 2 no halo
+// DMA, 4 no split of the raw tile (only together with 2: loads into dead registers are unsafe), 8 no unit-end waits /
+// barriers, 16 no MFMAs, 32 no operand reads
 template <int FL, int MT, int MODE, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   constexpr int NT = 2;
@@ -239,6 +239,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   using PR = Flavour<FL>;
   constexpr int NPX = PR::NPX, NPW = PR::NPW;
   constexpr int PLB = NPX * 2 * HALFB;          // bytes of one plane buffer
+  // PIPE: two plane buffers -- the split of chunk c+1 is interleaved with the MFMAs of chunk c (no phase (A), no barrier for
+  // it).  The bf16 x 3 flavour keeps one buffer and phase (A): two of its workgroups would not fit a CU otherwise.
+  constexpr bool PIPE = FL != 3;
+  constexpr int NPB = PIPE ? 2 : 1;
   constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
   constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
   constexpr int NWI = WUNIT / 1024;             // LDS-DMA instructions per unit
@@ -246,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned pl_base = lds0, w_base = lds0 + PLB, dummy = w_base + 2 * WUNIT, bias_lds = dummy + 1024;
+  const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + 2 * WUNIT, bias_lds = dummy + 1024;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -358,11 +362,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       cq[0] = __builtin_bit_cast(u32x2, h);
     }
   };
-  auto conv_store = [&](auto rr) __attribute__((always_inline)) {
+  auto conv_store = [&](auto rr, unsigned dst) __attribute__((always_inline)) {
     constexpr int R = decltype(rr)::value;
-    lds_write64<R * 1024>(cdst, cq[0]);
-    if constexpr (NPX >= 2) lds_write64<R * 1024 + 2 * HALFB>(cdst, cq[1]);
-    if constexpr (NPX >= 3) lds_write64<R * 1024 + 4 * HALFB>(cdst, cq[2]);
+    lds_write64<R * 1024>(dst, cq[0]);
+    if constexpr (NPX >= 2) lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
+    if constexpr (NPX >= 3) lds_write64<R * 1024 + 4 * HALFB>(dst, cq[2]);
   };
 
   // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, plane pl, channel tile mt;
@@ -370,14 +374,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   const unsigned abase = w_base + hi * 512 + j * 16;
   const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
   bf16x8 A[2][NPW][MT], Bq[2][NPX][NT];   // two operand sets: tap (dy, dx) multiplies set (dy + dx) & 1
+  bf16x8 Ad[MT];                          // f16 x 2: 2^-11 wA of the current tap
   constexpr int NLB = NPX * NT, NLA = NPW * MT;
   auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {   // aslot = abase + ring slot offset
     constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
     lds_read128<DX * WTAP + K * 1024>(A[SET][K / MT][K % MT], aslot);
   };
-  auto load_b = [&](auto setc, auto dyc, auto dxc, auto kc) __attribute__((always_inline)) {
+  auto load_b = [&](auto setc, auto dyc, auto dxc, auto kc, unsigned bcur) __attribute__((always_inline)) {   // bcur = bbase + plane buffer
     constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
-    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bbase);
+    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bcur);
   };
 
   const int co_lane = cb * MW + 4 * hi;
@@ -405,44 +410,66 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   for (int i = 0; i < NW_W; ++i) issue_w_piece(0u, i);
   issue_w_done();
   wait_vmcnt<0>();
+  if constexpr (PIPE) {   // chunk 0 -> plane buffer 0; the registers re-load with chunk 1
+    const bool more1 = !(ABL & 2) && G > 1;
+    if (more1) issue_in_begin();
+    static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
+      constexpr int R = decltype(rr)::value;
+      conv_split(rawr[R]);
+      conv_store(rr, cdst);
+      if (more1) issue_in_piece(rr);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
-  // Per chunk: (A) every wave splits its raw pieces into the planes (single buffer: the co-resident workgroup owns the
-  // matrix pipe meanwhile) and re-loads the registers for the next chunk; barrier; (B) three units (kernel rows) of three taps.
+  // Per chunk, bf16 x 3: (A) every wave splits its raw pieces into the planes (single buffer: the co-resident workgroup owns
+  // the matrix pipe meanwhile) and re-loads the registers for the next chunk; barrier; (B) three units (kernel rows) of three
+  // taps.  Other flavours (PIPE): no phase (A) -- split round R of the NEXT chunk (registers -> the other plane buffer, then
+  // the registers re-load with the chunk after that) rides in the MFMA groups of taps 1 and 2 of unit R / 2.
   // One tap = PR::N groups of MT*NT MFMAs, fenced by sched_barriers so that everything else stays where it is written: the
   // first groups read the next tap's operands (two sets, one tap ahead; the A operands of a unit's FIRST tap are read after
   // the barrier that publishes the unit's weights), the unit's first tap also issues the LDS-DMA pieces of the NEXT unit's
-  // weights, one per group.  Unit end: own LDS ops / DMAs done, barrier (publishes W(u+1), frees the planes / ring slot).
+  // weights, one per group.  Unit end: own LDS ops / weight DMAs done (the two raw loads issued after them may still fly),
+  // barrier (publishes W(u+1) and the other plane buffer, frees this one / the ring slot).
   constexpr int NG = PR::N;
   constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NG == 3 ? (NLA + NLB + 1) / 2 : NLA + NLB);   // operand reads per group
+  static_assert(NRAW_W == 6, "two split rounds per unit");
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const bool more_in = ABL != 2 && gc + 1 < G;
-      // ---- (A) split
+      // PIPE: the registers hold chunk gc+1 (if any); they re-load with chunk gc+2.  Else: they hold chunk gc, re-load with gc+1
+      const bool has_next = PIPE ? gc + 1 < G : true;
+      const bool more_in = !(ABL & 2) && gc + (PIPE ? 2 : 1) < G;
+      const unsigned pb = PIPE ? (unsigned)(gc & 1) * PLB : 0u;
+      const unsigned bcur = bbase + pb, cnext = PIPE ? cdst + (PLB - pb) : cdst;
       if (more_in) issue_in_begin();
-      if constexpr (ABL != 3) {
-        static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
-          constexpr int R = decltype(rr)::value;
-          conv_split(rawr[R]);
-          conv_store(rr);
-          if (more_in) issue_in_piece(rr);    // same slot of the next chunk
-        });
+      if constexpr (!PIPE) {
+        // ---- (A) split
+        if constexpr (!(ABL & 4)) {
+          static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
+            constexpr int R = decltype(rr)::value;
+            conv_split(rawr[R]);
+            conv_store(rr, cdst);
+            if (more_in) issue_in_piece(rr);    // same slot of the next chunk
+          });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
       // ---- (B) multiply
       static_for<0, 3>([&](auto dyc) __attribute__((always_inline)) {
         constexpr int dy = decltype(dyc)::value;
         const int u = 3 * gc + dy;
         const unsigned slot_cur = (u & 1) ? (unsigned)WUNIT : 0u, slot_nxt = (unsigned)WUNIT - slot_cur;
         const unsigned aslot = abase + slot_cur;
-        const bool do_w = ABL != 1 && u + 1 < 3 * G;     // weights of unit u+1 -> the other ring slot
+        const bool do_w = !(ABL & 1) && u + 1 < 3 * G;     // weights of unit u+1 -> the other ring slot
         // operands of the unit's first tap: A now (its weights were published by the barrier just passed); B too at dy == 0
         static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
           load_a(std::integral_constant<int, (dy & 1)>(), std::integral_constant<int, 0>(), kc, aslot);
         });
         if constexpr (dy == 0) {
           static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
-            load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc);
+            load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, bcur);
           });
         }
         static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
@@ -452,17 +479,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           __builtin_amdgcn_sched_barrier(0);
           static_for<0, NG>([&](auto gcnt) __attribute__((always_inline)) {
             constexpr int g = decltype(gcnt)::value;
-            if constexpr (ABL != 6) {
+            if constexpr (!(ABL & 32)) {
               // next tap's operands: (dy, dx+1): A and B; after the unit's last tap: only B of (dy+1, 0)
               static_for<g * LPG, (g + 1) * LPG < NLA + NLB ? (g + 1) * LPG : NLA + NLB>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 if constexpr (dx < 2) {
                   if constexpr (K < NLA) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), kc, aslot);
-                  else load_b(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>());
+                  else load_b(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>(), bcur);
                 } else if constexpr (dy < 2) {
                   if constexpr (K >= NLA)
                     load_b(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(),
-                           std::integral_constant<int, K - NLA>());
+                           std::integral_constant<int, K - NLA>(), bcur);
                 }
               });
             }
@@ -472,16 +499,37 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                 for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i);
               }
             }
-            if constexpr (ABL != 5) {
+            if constexpr (FL == 2 && g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                const f16x8 sc = {(_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE),
+                                  (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE)};
+                Ad[mt] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, A[set][0][mt]) * sc);
+              }
+            }
+            if constexpr (PIPE && dx >= 1 && g == NG / 2 && !(ABL & 4)) {   // split round R of the next chunk
+              constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
+              if (has_next) {
+                if constexpr (dy == 0) {
+                  if (gc == 0) wait_vmcnt<0>();   // (chunk 1's raw pieces were issued by the prologue: no unit end since)
+                }
+                conv_split(rawr[R]);
+                conv_store(std::integral_constant<int, R>(), cnext);
+                if (more_in) issue_in_piece(std::integral_constant<int, R>());
+              }
+            }
+            if constexpr (!(ABL & 16)) {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) {
+                  const bf16x8 av = PR::W[g] < NPW ? A[set][PR::W[g] < NPW ? PR::W[g] : 0][mt] : Ad[mt];
                   if constexpr (PR::F16)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[set][PR::W[g]][mt]),
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av),
                                                                          __builtin_bit_cast(f16x8, Bq[set][PR::X[g]][nt]), acc[mt][nt], 0, 0, 0);
                   else
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][PR::W[g]][mt], Bq[set][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, Bq[set][PR::X[g]][nt], acc[mt][nt], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -489,9 +537,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if (do_w) issue_w_done();
           }
         });
-        if (ABL != 4 && (u + 1 < 3 * G || true)) {
+        if (!(ABL & 8)) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          wait_vmcnt<0>();
+          if (PIPE && more_in) wait_vmcnt<2>();   // the weights of unit u+1 landed; this unit's two raw loads may still fly
+          else wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
         }
       });
@@ -679,14 +728,14 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
-  constexpr size_t ldsb = (size_t)(split::npx_of(NP) * 2 * split::HALFB) + 2 * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 + 256;   // planes, weight ring x2, dummy, bias
+  constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + 2 * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 + 256;   // planes (x2 when pipelined), weight ring x2, dummy, bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsb, dn)) == C2M_OK)
       hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
   };
-  if constexpr (NP == 3 && MT == 2) {
+  if constexpr (NP != 1 && MT == 2) {
     static const int abl = [] {
       const char* e = getenv("C2M_SPLIT_ABL");
       const int v = e ? atoi(e) : 0;
@@ -696,14 +745,15 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
     static unsigned long long done_abl[9] = {};
     if (abl > 0 && p.out_mode == 0) {
       switch (abl) {
-        case 1: go(&split::conv3x3_split_kernel<3, 2, 0, 1>, done_abl[1]); break;
-        case 2: go(&split::conv3x3_split_kernel<3, 2, 0, 2>, done_abl[2]); break;
-        case 3: go(&split::conv3x3_split_kernel<3, 2, 0, 3>, done_abl[3]); break;
-        case 4: go(&split::conv3x3_split_kernel<3, 2, 0, 4>, done_abl[4]); break;
-        case 5: go(&split::conv3x3_split_kernel<3, 2, 0, 5>, done_abl[5]); break;
-        case 6: go(&split::conv3x3_split_kernel<3, 2, 0, 6>, done_abl[6]); break;
-        case 7: go(&split::conv3x3_split_kernel<3, 2, 0, 7>, done_abl[7]); break;
-        default: go(&split::conv3x3_split_kernel<3, 2, 0, 8>, done_abl[8]); break;
+        case 1: go(&split::conv3x3_split_kernel<NP, 2, 0, 1>, done_abl[1]); break;
+        case 2: go(&split::conv3x3_split_kernel<NP, 2, 0, 2>, done_abl[2]); break;
+        case 6: go(&split::conv3x3_split_kernel<NP, 2, 0, 6>, done_abl[3]); break;
+        case 8: go(&split::conv3x3_split_kernel<NP, 2, 0, 8>, done_abl[4]); break;
+        case 32: go(&split::conv3x3_split_kernel<NP, 2, 0, 32>, done_abl[5]); break;
+        case 39: go(&split::conv3x3_split_kernel<NP, 2, 0, 39>, done_abl[6]); break;
+        case 47: go(&split::conv3x3_split_kernel<NP, 2, 0, 47>, done_abl[7]); break;
+        case 48: go(&split::conv3x3_split_kernel<NP, 2, 0, 48>, done_abl[8]); break;
+        default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL mask\n"); return C2M_ERR_INVALID_ARG;
       }
       return rc;
     }
