@@ -60,11 +60,11 @@ constexpr int NRAW_W = (NPIX * 4 + 255) / 256;  // 6 DMA instructions per wave: 
 constexpr int NRAW = 4 * NRAW_W;                // 24 slots (22 carry pixels; the rest read zeros) -- every wave runs the
                                                 // same branch-free sequence of DMAs and split rounds
 constexpr int RAW_BYTES = NRAW * 1024;
-constexpr int HALFB = NRAW * 256 + 64;          // one (plane, k half) slab: 384 pixels x 16 B + 64.  ds_write_b64 is serviced in groups
-                                                // of 16 consecutive lanes over 32 banks ((a/4) mod 32, MI355X_MICROARCH.md): a group of
-                                                // the split's stores covers 4 pixels x 16 B in each k-half slab -- == 64 mod 128 puts the
-                                                // two slabs on disjoint banks (with == 0 they collided 2-way: SQ_LDS_BANK_CONFLICT was 12 %
-                                                // of the LDS-active cycles)
+constexpr int HALFB = NPIX * 16;                // one (plane, k half) slab: 340 pixels x 16 B (the slots beyond are never stored).
+                                                // ds_write_b64 is serviced in groups of 16 consecutive lanes over 32 banks ((a/4) mod 32,
+                                                // MI355X_MICROARCH.md): a group of the split's stores covers 4 pixels x 16 B in each k-half
+                                                // slab -- == 64 mod 128 puts the two slabs on disjoint banks (with == 0 they collided 2-way:
+                                                // SQ_LDS_BANK_CONFLICT was 12 % of the LDS-active cycles)
 static_assert(HALFB % 128 == 64 && HALFB % 16 == 0, "bank phase of the second k half");
 
 // Flavour FL of the arithmetic: NPX input planes, NPW weight images, N piece products (weight image W[g] x input plane X[g]).
@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // it).  The bf16 x 3 flavour keeps one buffer and phase (A): two of its workgroups would not fit a CU otherwise.
   constexpr bool PIPE = FL != 3;
   constexpr int NPB = PIPE ? 2 : 1;
+  constexpr int NRING = PIPE ? 3 : 2;           // weight ring slots; unit u's weights are issued NRING-1 units ahead
   constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
   constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
   constexpr int NWI = WUNIT / 1024;             // LDS-DMA instructions per unit
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + 2 * WUNIT, bias_lds = dummy + 1024;
+  const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,11 +363,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       cq[0] = __builtin_bit_cast(u32x2, h);
     }
   };
+  const bool last_ok = (slotc[NRAW_W - 1] >> 24) != 0;   // the last round's slots reach beyond the 340 pixels of a slab
   auto conv_store = [&](auto rr, unsigned dst) __attribute__((always_inline)) {
     constexpr int R = decltype(rr)::value;
-    lds_write64<R * 1024>(dst, cq[0]);
-    if constexpr (NPX >= 2) lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
-    if constexpr (NPX >= 3) lds_write64<R * 1024 + 4 * HALFB>(dst, cq[2]);
+    if (R < NRAW_W - 1 || last_ok) {
+      lds_write64<R * 1024>(dst, cq[0]);
+      if constexpr (NPX >= 2) lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
+      if constexpr (NPX >= 3) lds_write64<R * 1024 + 4 * HALFB>(dst, cq[2]);
+    }
   };
 
   // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, plane pl, channel tile mt;
@@ -409,6 +413,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
   for (int i = 0; i < NW_W; ++i) issue_w_piece(0u, i);
   issue_w_done();
+  if constexpr (NRING == 3) {
+    if (3 * G > 1) {
+#pragma unroll
+      for (int i = 0; i < NW_W; ++i) issue_w_piece((unsigned)WUNIT, i);
+      issue_w_done();
+    }
+  }
   wait_vmcnt<0>();
   if constexpr (PIPE) {   // chunk 0 -> plane buffer 0; the registers re-load with chunk 1
     const bool more1 = !(ABL & 2) && G > 1;
@@ -433,8 +444,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // weights, one per group.  Unit end: own LDS ops / weight DMAs done (the two raw loads issued after them may still fly),
   // barrier (publishes W(u+1) and the other plane buffer, frees this one / the ring slot).
   constexpr int NG = PR::N;
-  constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NG == 3 ? (NLA + NLB + 1) / 2 : NLA + NLB);   // operand reads per group
+#ifndef C2M_LPGD
+#define C2M_LPGD 2
+#endif
+  constexpr int LPGD = C2M_LPGD;
+  constexpr int LPG = NG >= 4 ? (NLA + NLB + NG - 3) / (NG - 2) : (NG == 3 ? (NLA + NLB + LPGD - 1) / LPGD : NLA + NLB);   // operand reads per group
   static_assert(NRAW_W == 6, "two split rounds per unit");
+  unsigned slot_cur = 0u;   // ring slot (byte offset) of the current unit
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       // PIPE: the registers hold chunk gc+1 (if any); they re-load with chunk gc+2.  Else: they hold chunk gc, re-load with gc+1
@@ -460,9 +476,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       static_for<0, 3>([&](auto dyc) __attribute__((always_inline)) {
         constexpr int dy = decltype(dyc)::value;
         const int u = 3 * gc + dy;
-        const unsigned slot_cur = (u & 1) ? (unsigned)WUNIT : 0u, slot_nxt = (unsigned)WUNIT - slot_cur;
+        // weights of unit u + NRING - 1 -> the slot unit u - 1 has just left
+        const unsigned slot_nxt = slot_cur == 0u ? (unsigned)((NRING - 1) * WUNIT) : slot_cur - (unsigned)WUNIT;
         const unsigned aslot = abase + slot_cur;
-        const bool do_w = !(ABL & 1) && u + 1 < 3 * G;     // weights of unit u+1 -> the other ring slot
+        const bool do_w = !(ABL & 1) && u + NRING - 1 < 3 * G;
         // operands of the unit's first tap: A now (its weights were published by the barrier just passed); B too at dy == 0
         static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
           load_a(std::integral_constant<int, (dy & 1)>(), std::integral_constant<int, 0>(), kc, aslot);
@@ -522,7 +539,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+                for (int nq = 0; nq < NT; ++nq) {
+                  const int nt = nq;
                   const bf16x8 av = PR::W[g] < NPW ? A[set][PR::W[g] < NPW ? PR::W[g] : 0][mt] : Ad[mt];
                   if constexpr (PR::F16)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av),
@@ -539,10 +557,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
         });
         if (!(ABL & 8)) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (PIPE && more_in) wait_vmcnt<2>();   // the weights of unit u+1 landed; this unit's two raw loads may still fly
-          else wait_vmcnt<0>();
+          // PIPE, steady state: the weights of unit u+1 (issued in unit u-1) landed, and with them every raw load older than
+          // unit u-1's; still in flight may be: raw(u-1) x 2, W(u+2) x NW_W, raw(u) x 2.  (vmcnt counts in issue order.)
+          if (PIPE && more_in) {
+            if ((ABL & 128) && c == 0 && dy == 0) wait_vmcnt<4 + NW_W + 16>();
+            else wait_vmcnt<4 + NW_W>();
+          } else wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
         }
+        slot_cur = slot_cur == (unsigned)((NRING - 1) * WUNIT) ? 0u : slot_cur + (unsigned)WUNIT;
       });
     }
     // ----------------------------------------------------------------------------------------------------------------
@@ -563,7 +586,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             else acc[mt][nt][4 * qd + e] += bv[e];
           }
       }
-    if constexpr (MODE == 3) {
+    if constexpr ((ABL & 64) != 0) {
+      // (ablation: one 16-byte store per lane and tile -- the sum of its accumulators -- instead of sixteen)
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r & 3] += acc[mt][nt][r];
+      const int y = y0 + 2 * wv, x = x0 + j;
+      if (y < p.H && x < p.W)
+        *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co_lane) = v;
+    } else if constexpr (MODE == 3) {
       float asum = 0.0f;
       const HeadOut ho = head_out(p, b);
 #pragma unroll
@@ -728,7 +763,8 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
-  constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + 2 * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 + 256;   // planes (x2 when pipelined), weight ring x2, dummy, bias
+  constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + (NP != 3 ? 3 : 2) * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 +
+                          256;   // planes (x2 when pipelined), weight ring (3 / 2 slots), dummy, bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {
@@ -742,7 +778,7 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
       if (v > 0) fprintf(stderr, "c2m: C2M_SPLIT_ABL=%d -- conv3x3 split kernel runs a timing-only ablation, its results are wrong\n", v);
       return v;
     }();
-    static unsigned long long done_abl[9] = {};
+    static unsigned long long done_abl[13] = {};
     if (abl > 0 && p.out_mode == 0) {
       switch (abl) {
         case 1: go(&split::conv3x3_split_kernel<NP, 2, 0, 1>, done_abl[1]); break;
@@ -753,6 +789,10 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
         case 39: go(&split::conv3x3_split_kernel<NP, 2, 0, 39>, done_abl[6]); break;
         case 47: go(&split::conv3x3_split_kernel<NP, 2, 0, 47>, done_abl[7]); break;
         case 48: go(&split::conv3x3_split_kernel<NP, 2, 0, 48>, done_abl[8]); break;
+        case 64: go(&split::conv3x3_split_kernel<NP, 2, 0, 64>, done_abl[9]); break;
+        case 128: go(&split::conv3x3_split_kernel<NP, 2, 0, 128>, done_abl[10]); break;
+        case 111: go(&split::conv3x3_split_kernel<NP, 2, 0, 111>, done_abl[11]); break;
+        case 112: go(&split::conv3x3_split_kernel<NP, 2, 0, 112>, done_abl[12]); break;
         default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL mask\n"); return C2M_ERR_INVALID_ARG;
       }
       return rc;

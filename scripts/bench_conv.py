@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--fast", action="store_true", help="fast=True: the decoder's setting (split-bf16 kernel; with C2M_CONV_SPLIT=0 the "
                                                         "Winograd F(4,3) kernel where the map allows)")
+    ap.add_argument("--data", type=str, default="randn", help="randn | zeros | ones (power / clock experiments: the matrix pipe draws less on constant data)")
     ap.add_argument("--algo", type=str, default=None, help="force direct / winograd / winograd4 / split / bf16")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -42,6 +43,10 @@ def main():
         xs = [torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last) for c in cins]
         w = torch.randn(co, sum(cins), 3, 3, device=dev) * 0.02
         b = torch.randn(co, device=dev)
+        if args.data != "randn":
+            fill = 0.0 if args.data == "zeros" else 1.0
+            xs = [x.fill_(fill) for x in xs]
+            w.fill_(fill * 0.02)
         flow = torch.zeros(B, hw // (hw // 160) - 2, hw // (hw // 160) - 2, 2, device=dev)
 
         def run():
