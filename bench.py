@@ -167,7 +167,7 @@ def conv_rooflines(kern, fam, steps, pmc):
     """The 3x3 convolutions of one step, split by the matrix pipe they run on.  fam = ops.conv_flops_by_family() of the
     timed steps: {family: [launches, algorithmic flops, executed matrix flops]}."""
     out = []
-    for kid, pipe, peak in (("conv3x3_split", "bf16 MFMA", BF16_MATRIX_PEAK_TFLOPS), ("conv3x3_mfma", "fp32 MFMA", FP32_MATRIX_PEAK_TFLOPS)):
+    for kid, pipe, peak in (("conv3x3_split", "f16 / bf16 MFMA", BF16_MATRIX_PEAK_TFLOPS), ("conv3x3_mfma", "fp32 MFMA", FP32_MATRIX_PEAK_TFLOPS)):
         ms = kern.get(kid, [])
         if not ms:
             continue
@@ -176,8 +176,10 @@ def conv_rooflines(kern, fam, steps, pmc):
         execd = sum(v[2] for v in mine.values()) / steps
         kms = sum(ms) / steps
         e = {"bound": "mfma", "pipe": pipe,
-             "kernel": ("conv3x3_split_kernel (csrc/conv3x3_split.hip: fp32-accurate 3x3 convolution on the bf16 matrix pipe -- three "
-                        "exact bf16 pieces per operand, six MFMAs per product sum; decoder, DCN heads, VGG19 taps, extractor towers)"
+             "kernel": ("conv3x3_split_kernel (csrc/conv3x3_split.hip: fp32-accurate 3x3 convolution on the 16-bit matrix pipe.  fp32 "
+                        "inference: f16 x 2 flavour -- activations as two round-to-nearest f16 pieces, weights scaled per tensor and "
+                        "split the same way, THREE MFMAs per product sum; autograd / $C2M_CONV_SPLIT16=0: bf16 x 3 flavour, six MFMAs; "
+                        "bf16 autocast: one piece, one MFMA.  Decoder, DCN heads, VGG19 taps, extractor towers)"
                         if kid == "conv3x3_split" else
                         "conv3x3_kernel / conv3x3_wino*_kernel / conv3x3_c3_kernel (csrc/conv3x3.hip, fp32 MFMA: first layers of "
                         "the image towers and whatever $C2M_CONV_SPLIT keeps off the split kernel)"),
@@ -192,7 +194,9 @@ def conv_rooflines(kern, fam, steps, pmc):
         if kid == "conv3x3_split":
             e["frac_of_sustained_bf16_rate"] = _tf(execd, kms) / BF16_SUSTAINED_TFLOPS
             e["sustained_note"] = ("back-to-back v_mfma_f32_32x32x16_bf16 on every SIMD with non-zero operands sustains "
-                                   f"{BF16_SUSTAINED_TFLOPS:.0f} TF on this chip (power: ~1.7 GHz), scripts/ubench/mfma_bf16_rate.hip")
+                                   f"{BF16_SUSTAINED_TFLOPS:.0f} TF on this chip (power: ~1.7 GHz), scripts/ubench/mfma_bf16_rate.hip.  "
+                                   "The kernel itself is POWER-bound on random data: the 64->64 @640^2 layer takes 1.60 ms on N(0,1) "
+                                   "tensors and 1.13 ms on all-zero ones (same instruction stream), profiles/r03_power_experiment.txt")
         out.append(e)
     return out
 
@@ -358,6 +362,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default 16; 4 for --workload train and --lr 320)")
     ap.add_argument("--lr", type=int, default=None, help="LR size = feature-map size (default 160; 40 for --workload train)")
     ap.add_argument("--workload", choices=("restore", "corr", "train"), default="restore")
+    ap.add_argument("--graph", choices=("0", "1"), default="0",
+                    help="train workload: capture the training step into a hipGraph (train.hip_graph; one process only).  Measured on "
+                         "configs[3]: 33.1 ms against 31.7 ms eager -- the step is GPU-bound, not launch-bound -- hence off by default")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra passes on the other convolution arithmetics")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="bf16: inference under torch.autocast(bfloat16) (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -453,7 +461,10 @@ def main():
                                "vgg_layer_list": ["relu1_1", "relu2_1", "relu3_1"], "vgg_type": "vgg19"},
                "network_extractor": {"type": "ContrasExtractorSep"},
                "train": {"lr_g": 1e-4, "lr_offset": 1e-4, "lr_relu2_offset": 1e-5, "lr_relu3_offset": 1e-6,
-                         "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0}}
+                         "weight_decay_g": 0, "beta_g": [0.9, 0.999], "pixel_weight": 1.0,
+                         "hip_graph": dist is None and args.graph == "1"}}
+        if args.warmup < 4 and opt["train"]["hip_graph"]:
+            raise SystemExit("--workload train with the hipGraph step needs --warmup >= 4 (2 eager steps + capture + 1 replay)")
         torch.manual_seed(10)     # same initial weights on every rank (DDP broadcasts rank 0's anyway)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
@@ -481,7 +492,7 @@ def main():
                             "parallelism": f"dp{world}" + (" (DDP over RCCL: one all-reduce of net_g's gradients per step, bucketed, "
                                                           "overlapped with backward)" if dist is not None else " (single process)")},
                     gradient_allreduce_bytes_per_step_per_gpu=grad_bytes if dist is not None else 0,
-                    net_g_gradient_bytes=grad_bytes, loss=float(loss),
+                    net_g_gradient_bytes=grad_bytes, loss=float(loss), hip_graph=bool(opt["train"]["hip_graph"]),
                     c2m_kernel_ms_per_step={k: sum(v) / args.steps for k, v in kern.items()})
         return finish(line)
 
@@ -583,6 +594,35 @@ def main():
                     dtype="bf16" if bf16 else "f32",
                     config={"workload": cfg, "parallelism": f"dp{world} (batch-sharded, no collective)"},
                     stage_ms=stage, roofline=dominant, roofline_kernels=rl, configs1_corr_only=sub)
+        if not bf16:
+            line["arithmetic"] = (
+                "fp32 tensors end to end, fp32 accumulation everywhere.  Correlation / arg-max and DCNv2: fp32 MFMA.  3x3 convolutions: "
+                "every fp32 operand enters the f16 matrix pipe as two round-to-nearest f16 pieces (x = x0 + 2^-11 x1'; weights scaled "
+                "per tensor by a power of two), three products per product sum -- measured error against float64 <= 1.5x that of the "
+                "exact-fp32-MFMA kernel at the tolerance of the other fp32 kernels (tests/test_conv_gpu.py: 1e-5 * scale); "
+                "$C2M_CONV_SPLIT16=0 runs the bf16 x 3 flavour (six products, full fp32 exponent range), $C2M_CONV_SPLIT=0 the "
+                "fp32-MFMA kernels -- `value_other_conv_arithmetic` times the same step with them")
+            if not args.no_alt:
+                # the same step on the other convolution arithmetics (outside the timed region of `value`)
+                from c2m_amd import ops as _ops
+                alt = {}
+                for name, (s16, spl) in (("bf16x3_six_products", (False, _ops._SPLIT)), ("fp32_mfma_direct_winograd", (False, "0"))):
+                    keep = (_ops._SPLIT16, _ops._SPLIT)
+                    _ops._SPLIT16, _ops._SPLIT = s16, spl
+                    try:
+                        it[0] = 0
+                        restore_step()
+                        sync()
+                        it[0] = 0
+                        t0 = time.perf_counter()
+                        for _ in range(min(args.steps, 5)):
+                            it[0] = 0
+                            restore_step()
+                        sync()
+                        alt[name] = B * world * min(args.steps, 5) / (time.perf_counter() - t0)
+                    finally:
+                        _ops._SPLIT16, _ops._SPLIT = keep
+                line["value_other_conv_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline and not bf16:
             idx_gpu = last["pre"].max_idx.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline_restore(ext, mp, net, lq, up, ref, sr, idx_gpu)

@@ -113,7 +113,7 @@ class _OffsetMeanWatch:
 
     def poll(self):
         pending = self._pending   # read once: DataParallel replicas share this object across threads
-        if pending is not None:
+        if pending is not None and not torch.cuda.is_current_stream_capturing():
             host, event, numel = pending
             if event.query():
                 mean = float(host.sum()) / numel
@@ -123,6 +123,8 @@ class _OffsetMeanWatch:
                     self._pending = None
 
     def push(self, abs_sum, numel):
+        if torch.cuda.is_current_stream_capturing():
+            return   # (a hipGraph capture of the training step: no pinned allocation / event query inside it)
         if self._pending is None:
             host = torch.empty(_ABS_SLOTS, dtype=torch.float64, pin_memory=True)
             host.copy_(abs_sum, non_blocking=True)

@@ -8,6 +8,13 @@ Validation: ``nondist_validation`` computes PSNR / PSNR_Y /
 (ref_restoration_model.py:295-370) but on the device (mmsr/utils/metrics.py here: three scalars per image cross PCIe
 instead of two full images); ``dist_validation`` -- which in the reference calls a method that does not exist
 (sr_model.py:160-162) -- shards the loader over the ranks and all-reduces the sums.
+
+MI355X addition -- ``train: {hip_graph: true}`` (single-process training): the whole training step (extractor +
+correspondence + net_g forward + L1 + backward + Adam) is a launch-bound chain of ~1500 small kernels at the reference's
+stage-3 crop size (GT 160x160, batch 4 per GPU): the host spends more time launching than the GPU computing.  The step is
+captured once into a hipGraph (torch.cuda.CUDAGraph: static input buffers filled by ``feed_data``, Adam in capturable
+mode, two eager warm-up steps so that allocator, MIOpen find and lazy initialisation stay outside the capture) and
+replayed per ``optimize_parameters`` call -- same arithmetic, same kernels, one launch.
 """
 import copy
 import logging
@@ -37,6 +44,9 @@ class RefRestorationModel(BaseModel):
             self.load_network(self.net_extractor, path['pretrain_model_feature_extractor'], path.get('strict_load', True))
         if path.get('pretrain_model_g'):
             self.load_network(self.net_g, path['pretrain_model_g'], path.get('strict_load', True))
+        self._graph_on = bool(self.is_train and (self.opt.get('train') or {}).get('hip_graph') and not self.opt.get('dist')
+                              and self.device.type == 'cuda')
+        self._graph, self._graph_calls, self._static = None, 0, None
         if self.is_train:
             self.net_g.train()
             self._build_optimizer()
@@ -60,10 +70,25 @@ class RefRestorationModel(BaseModel):
              {'params': groups['offset'], 'lr': t['lr_offset']},
              {'params': groups['relu3_offset'], 'lr': t['lr_relu3_offset']},
              {'params': groups['relu2_offset'], 'lr': t['lr_relu2_offset']}],
-            lr=t['lr_g'], weight_decay=t.get('weight_decay_g', 0), betas=tuple(t['beta_g']))
+            lr=t['lr_g'], weight_decay=t.get('weight_decay_g', 0), betas=tuple(t['beta_g']),
+            capturable=self._graph_on)   # (step counters on the device: required inside a captured step)
         self.optimizers.append(self.optimizer_g)
 
+    _FEED = (('img_in_lq', 'img_in_lq'), ('img_ref', 'img_ref'), ('gt', 'img_in'), ('match_img_in', 'img_in_up'))
+
     def feed_data(self, data):
+        if self._graph_on:
+            # static input buffers: the captured step reads these addresses; a new batch is copied INTO them
+            shapes = {a: tuple(data[k].shape) for a, k in self._FEED}
+            if self._static is None or {a: tuple(t.shape) for a, t in self._static.items()} != shapes:
+                self._static = {a: data[k].to(self.device, copy=True) for a, k in self._FEED}
+                self._graph, self._graph_calls = None, 0    # new geometry: capture again
+            else:
+                for a, k in self._FEED:
+                    self._static[a].copy_(data[k], non_blocking=True)
+            for a, _ in self._FEED:
+                setattr(self, a, self._static[a])
+            return
         self.img_in_lq = data['img_in_lq'].to(self.device)
         self.img_ref = data['img_ref'].to(self.device)
         self.gt = data['img_in'].to(self.device)
@@ -75,6 +100,11 @@ class RefRestorationModel(BaseModel):
             self.pre_offset, self.img_ref_feat = self.net_map(self.features, self.img_ref)
 
     def optimize_parameters(self, step):
+        if self._graph_on:
+            return self._optimize_graphed()
+        self._train_step()
+
+    def _train_step(self):
         self._correspondence()
         self.output = self.net_g(self.img_in_lq, self.pre_offset, self.img_ref_feat)
         self.optimizer_g.zero_grad()
@@ -82,6 +112,31 @@ class RefRestorationModel(BaseModel):
         l_pix.backward()  # DCNv2 backward x3; DDP all-reduces net_g's gradients (RCCL) while it runs
         self.optimizer_g.step()
         self.log_dict['l_g_pix'] = l_pix.detach()  # no .item(): the reference's per-step host sync is dropped
+
+    GRAPH_WARMUP_STEPS = 2
+
+    def _optimize_graphed(self):
+        """Every call is exactly one training step: the first GRAPH_WARMUP_STEPS run eagerly on a side stream, the next one
+        captures the step and replays it once, later ones only replay.  log_dict / output / the parameters' .grad keep
+        their addresses: each replay rewrites them in place."""
+        if self._graph is not None:
+            self._graph.replay()
+            return
+        self._graph_calls += 1
+        cur = torch.cuda.current_stream()
+        if self._graph_calls <= self.GRAPH_WARMUP_STEPS:
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._train_step()
+            cur.wait_stream(side)
+            return
+        self.optimizer_g.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._train_step()
+        self._graph = graph
+        graph.replay()
 
     # ---------------------------------------------------------------- validation
     def _validate_shard(self, dataloader, rank, world):

@@ -75,8 +75,8 @@ out = {
             "(GRBM_GUI_ACTIVE / 8 XCDs), summed over the launches of the run.",
 }
 json.dump(out, open(os.path.join(REPO, "profiles", "step_pmc_traffic.json"), "w"), indent=1)
-for name in ("bench_default", "bench_corr", "bench_conv", "bench_dcn", "bench_train", "bench_train_lr96", "bench_train_rccl_1rank",
-             "bench_cfg5_bf16", "bench_cfg5_f32", "bench_selfspawn_1gpu", "ubench_mfma_bf16_rate", "pytest_gpu", "smoke"):
+for name in ("bench_default", "bench_corr", "bench_conv", "bench_dcn", "bench_train", "bench_train_lr96", "bench_train_hipgraph", "bench_train_rccl_1rank",
+             "bench_cfg5_bf16", "bench_cfg5_f32", "bench_selfspawn_1gpu", "ubench_mfma_bf16_rate", "power_experiment", "pytest_gpu", "smoke"):
     src = os.path.join(SRC, name + ".log")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(REPO, "profiles", f"{tag}_{name}.log"))

@@ -492,6 +492,60 @@ def test_ddp_nccl_wrapped_net_g_step_and_test_match_the_bare_module(dev):
         dist.destroy_process_group()
 
 
+def test_hip_graph_training_step_matches_the_eager_step(dev):
+    """train.hip_graph: the captured-and-replayed training step (2 eager warm-up steps, capture, replays; static input buffers
+    refilled by feed_data) walks the same trajectory as the eager loop: per-step losses and the parameters after 6 steps on 6
+    different batches agree to the run-to-run noise of the fp32 atomics in the DCNv2 weight gradients."""
+    from mmsr.models.base_model import unwrap
+    from mmsr.models.ref_restoration_model import RefRestorationModel
+    import mmsr.models.archs.ref_restoration_arch as arch
+    arch._TRAIN_KERNELS = "1"   # hand-written convolution kernels (deterministic) in both runs
+    try:
+        torch.manual_seed(12)
+        eager = RefRestorationModel(_train_opt(False))
+        for stage in ("small", "medium", "large"):
+            torch.nn.init.normal_(getattr(unwrap(eager.net_g).dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask.weight, std=0.01)
+        opt = _train_opt(False)
+        opt["train"]["hip_graph"] = True
+        graphed = RefRestorationModel(opt)
+        assert graphed._graph_on and not eager._graph_on
+        for dst, src in ((graphed.net_g, eager.net_g), (graphed.net_map, eager.net_map), (graphed.net_extractor, eager.net_extractor)):
+            dst.load_state_dict(src.state_dict())
+        losses = []
+        for step in range(1, 7):
+            data = _train_batch(B=2, h=16, seed=4200 + 10 * step)
+            for m in (eager, graphed):
+                m.feed_data(data)
+                m.optimize_parameters(step)
+            torch.cuda.synchronize()
+            losses.append((float(eager.log_dict["l_g_pix"]), float(graphed.log_dict["l_g_pix"])))
+        assert graphed._graph is not None
+        for le, lg in losses:
+            assert abs(le - lg) <= 1e-4 * abs(le), losses
+        assert len({round(le, 6) for le, _ in losses}) > 3          # the batches really differed
+        # parameters: Adam normalises every gradient entry, so entries whose gradient is atomics-noise can walk apart by up to
+        # 2 * lr per step between ANY two runs; the bulk must coincide
+        worst, moved, same = 0.0, 0, 0
+        for (k, pe), (_, pg) in zip(eager.net_g.named_parameters(), graphed.net_g.named_parameters()):
+            d = (pe.detach() - pg.detach()).abs()
+            worst = max(worst, float(d.max()))
+            moved += int((d > 1e-5).sum())
+            same += d.numel()
+        assert worst <= 2 * 6 * 1e-4 + 1e-6, worst
+        assert moved < 0.02 * same, (moved, same)
+        # a new geometry drops the graph and captures again
+        graphed.feed_data(_train_batch(B=1, h=16, seed=4300))
+        assert graphed._graph is None
+        for step in range(7, 11):
+            graphed.optimize_parameters(step)
+        torch.cuda.synchronize()
+        assert graphed._graph is not None and bool(torch.isfinite(graphed.log_dict["l_g_pix"]))
+        sr = graphed.test()                                         # the fused inference path still runs beside the graph
+        assert bool(torch.isfinite(sr).all())
+    finally:
+        arch._TRAIN_KERNELS = "auto"
+
+
 def test_dataparallel_scatter_keeps_the_fused_path(dev):
     """nn.DataParallel (the reference's default without a launcher, base_model.py:73-74) rebuilds dict inputs per replica:
     PreOffsets must come out as PreOffsets (sliced index map), so the replica still takes the fused path."""
