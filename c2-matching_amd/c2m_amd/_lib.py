@@ -80,6 +80,7 @@ def _declare(L):
     L.c2m_conv3x3_relayout_split_bytes.argtypes = [_i, _i, _i]
     L.c2m_conv3x3_relayout_split_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     L.c2m_conv3x3_relayout_split_dgrad_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
+    L.c2m_conv3x3_relayout_split_multi.argtypes = [_vp, _vp, _i, ctypes.c_longlong, _i]
     L.c2m_conv3x3_wgrad_workspace_bytes.restype = _sz
     L.c2m_conv3x3_wgrad_workspace_bytes.argtypes = [_i] * 5
     L.c2m_conv3x3_wgrad_f32.argtypes = [_vp, ctypes.POINTER(ConvSrc), _i, _vp, _i, _i, ctypes.c_longlong] + [_i] * 5 + [_vp, _vp, _sz]

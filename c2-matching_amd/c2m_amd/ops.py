@@ -269,6 +269,7 @@ class _WeightCache:
 
     def __init__(self):
         self._d = {}
+        self._tables = {}    # refresh job tables: frozenset(param ids) | None -> (signature, device int64 [n, 8], nblocks, any_f16)
 
     def _lookup(self, slot, key, weight):
         hit = self._d.get(slot)
@@ -288,18 +289,51 @@ class _WeightCache:
 
     def clear(self):
         self._d.clear()
+        self._tables.clear()
+
+    _SPLIT_PIECES = {3: 3, 4: 1, 5: 3, 6: 2}     # cache kind -> pieces of the split-kernel image
 
     def refresh(self, param_ids=None):
-        """Re-run the re-layout kernels of the live entries (of the tensors whose id() is in param_ids, or all)."""
+        """Re-run the re-layout of the live entries (of the tensors whose id() is in param_ids, or all) from the tensors'
+        current contents.  The split-kernel images -- nearly all of them -- go through ONE multi-tensor call
+        (c2m_conv3x3_relayout_split_multi: a device job table, rebuilt only when the set of images changes); the rest
+        (fp32-MFMA kernels' layouts, padded input channels) one call per image."""
         n = 0
+        jobs, sig, dev = [], [], None
         for slot, (key, value, ref, redo) in list(self._d.items()):
             w = ref()
             if w is None or redo is None or (param_ids is not None and id(w) not in param_ids):
                 continue
             if key[0] != w.data_ptr() or key[1] != w._version:
                 continue        # stale by key: the next get() rebuilds it anyway
-            redo(w, value)
+            rows, kind = (slot[1], slot[2]) if isinstance(slot, tuple) and len(slot) == 3 else (None, None)
+            if kind in self._SPLIT_PIECES and len(key) == 5 and key[3] is None and w.is_contiguous() and (dev is None or dev == w.device):
+                dev = w.device
+                Co, Ci = (rows[1] - rows[0] if rows is not None else w.shape[0]), w.shape[1]
+                cin_k, cout_k = (Co, Ci) if kind == 5 else (Ci, Co)      # the data-gradient conv swaps the roles
+                pieces = self._SPLIT_PIECES[kind]
+                nbytes = _lib.lib().c2m_conv3x3_relayout_split_bytes(cin_k, cout_k, pieces) - (256 if pieces == 2 else 0)
+                wptr = w.data_ptr() + (rows[0] * Ci * 9 * 4 if rows is not None else 0)
+                jobs.append((wptr, value.data_ptr(), cin_k, cout_k, pieces | ((1 if cout_k <= 32 else 2) << 8) | ((1 if kind == 5 else 0) << 16),
+                             nbytes // 2))
+                sig.append((slot, wptr, value.data_ptr()))
+            else:
+                redo(w, value)
             n += 1
+        if jobs:
+            tkey = None if param_ids is None else frozenset(param_ids)
+            sig = tuple(sig)
+            tab = self._tables.get(tkey)
+            if tab is None or tab[0] != sig:
+                rowsl, first = [], 0
+                for (wptr, iptr, ci, co, flags, elems) in jobs:
+                    rowsl.append([wptr, iptr, ci, co, flags, elems, first, 0])
+                    first += (elems + 255) // 256
+                tab = (sig, torch.tensor(rowsl, dtype=torch.int64).to(dev), first, int(any((j[4] & 0xff) == 2 for j in jobs)))
+                self._tables[tkey] = tab
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().c2m_conv3x3_relayout_split_multi(_stream(), tab[1].data_ptr(), len(jobs), tab[2], tab[3]),
+                           "c2m_conv3x3_relayout_split_multi")
         return n
 
     @staticmethod

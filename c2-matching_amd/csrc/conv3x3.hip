@@ -1394,6 +1394,7 @@ namespace conv {   // conv3x3_split.hip
 size_t split_relayout_bytes(int Cin, int Cout, int np);
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad);
 int launch_split(hipStream_t st, Params p, int np);
+int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long long nblocks, int any_f16);
 }  // namespace conv
 }  // namespace c2m
 
@@ -1402,6 +1403,10 @@ extern "C" size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces
 extern "C" int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr) {
   if (!weight || !wr) return C2M_ERR_INVALID_ARG;
   return conv::split_relayout(as_stream(stream), weight, Cin, Cout, pieces, wr, 0);
+}
+
+extern "C" int c2m_conv3x3_relayout_split_multi(c2m_stream_t stream, const long long* jobs, int njobs, long long nblocks, int any_f16) {
+  return conv::split_relayout_multi(as_stream(stream), jobs, njobs, nblocks, any_f16);
 }
 
 extern "C" int c2m_conv3x3_relayout_split_dgrad_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr) {

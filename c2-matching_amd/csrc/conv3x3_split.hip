@@ -153,14 +153,17 @@ __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) 
 // value = piece `plane` of W[cb*32*MT + mt*32 + row][chunk*16 + 8*half + e][dy][dx] (0 beyond Cout)
 // dgrad != 0: images of the DATA-GRADIENT convolution instead (Cin/Cout = its input/output channels = the forward's
 // Cout/Cin): value = piece of w[ci][co][2-dy][2-dx] with w the forward weight [Cin here][Cout here][3][3]
-// fl = 2: the image is followed by a 256-byte tail {float 1/S, uint bits of max |w| (written by weight_absmax_kernel)}
-__global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float* __restrict__ w, int Cin, int Cout, int fl, int MT,
-                                                                      long long total, unsigned short* __restrict__ wr, int dgrad) {
+// fl = 2: the image is followed by a 256-byte tail of 32-bit slots: [0] float 1/S; uint bits of max |w|: [3] written by
+// weight_absmax_kernel (single-tensor path: zeroed + atomicMax), [8 .. 8 + ABSMAX_SPLIT) partial maxima of
+// weight_absmax_multi_kernel (each overwritten by its own workgroup: nothing to zero, no atomics)
+__device__ __forceinline__ void relayout_split_elem(const float* __restrict__ w, int Cin, int Cout, int fl, int MT, long long total,
+                                                    unsigned short* __restrict__ wr, int dgrad, long long e0, int max_slot, int nslot) {
   const int NP = npw_of(fl);
-  const long long e0 = (long long)blockIdx.x * 256 + threadIdx.x;
   float S = 1.0f;
   if (fl == 2) {
-    S = f16_weight_scale(__builtin_bit_cast(float, reinterpret_cast<const unsigned*>(wr + total)[1]));
+    unsigned mx = 0;
+    for (int i = 0; i < nslot; ++i) mx = max(mx, reinterpret_cast<const unsigned*>(wr + total)[max_slot + i]);
+    S = f16_weight_scale(__builtin_bit_cast(float, mx));
     if (e0 == 0) reinterpret_cast<float*>(wr + total)[0] = 1.0f / S;
   }
   if (e0 >= total) return;
@@ -179,14 +182,49 @@ __global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float
   wr[e0] = fl == 2 ? f16_piece(v, pl, S) : bf16_piece(v, pl, fl == 1);
 }
 
-// max |w| as uint bits (monotonic for non-negative floats; NaN -> large) into slot[1], zeroed by the caller
-__global__ void __launch_bounds__(256) weight_absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ slot) {
+__global__ void __launch_bounds__(256) conv3x3_relayout_split_kernel(const float* __restrict__ w, int Cin, int Cout, int fl, int MT,
+                                                                      long long total, unsigned short* __restrict__ wr, int dgrad) {
+  relayout_split_elem(w, Cin, Cout, fl, MT, total, wr, dgrad, (long long)blockIdx.x * 256 + threadIdx.x, 3, 1);
+}
+
+// max |w| as uint bits (monotonic for non-negative floats; NaN -> large) of this thread's share, reduced over its wave
+__device__ __forceinline__ unsigned absmax_wave(const float* __restrict__ w, long long n, long long first, long long stride) {
   unsigned m = 0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    m = max(m, __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu);
+  for (long long i = first; i < n; i += stride) m = max(m, __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + 1, m);
+  return m;
+}
+__global__ void __launch_bounds__(256) weight_absmax_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ slot) {
+  const unsigned m = absmax_wave(w, n, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + 3, m);   // (slot zeroed by the caller)
+}
+
+// ---- many tensors per launch (the per-forward refresh of a module's cached images: ~160 weights) ------------------------
+// job = 8 x int64: {weight ptr, image ptr, Cin, Cout, fl | MT << 8 | dgrad << 16, image elements, first block, -}
+constexpr int ABSMAX_SPLIT = 8;
+__global__ void __launch_bounds__(256) weight_absmax_multi_kernel(const long long* __restrict__ jobs) {
+  const long long* jb = jobs + (size_t)blockIdx.x * 8;
+  if ((int)(jb[4] & 0xff) != 2) return;
+  const long long n = jb[2] * jb[3] * 9;
+  const unsigned m = absmax_wave(reinterpret_cast<const float*>(jb[0]), n, (long long)blockIdx.y * 256 + threadIdx.x, (long long)ABSMAX_SPLIT * 256);
+  __shared__ unsigned part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    (reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(jb[1]) + jb[5]))[8 + blockIdx.y] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+__global__ void __launch_bounds__(256) conv3x3_relayout_split_multi_kernel(const long long* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;            // last job whose first block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[(size_t)mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* jb = jobs + (size_t)lo * 8;
+  const int flags = (int)jb[4];
+  relayout_split_elem(reinterpret_cast<const float*>(jb[0]), (int)jb[2], (int)jb[3], flags & 0xff, (flags >> 8) & 0xff, jb[5],
+                      reinterpret_cast<unsigned short*>(jb[1]), (flags >> 16) & 1, ((long long)blockIdx.x - jb[6]) * 256 + threadIdx.x, 8,
+                      ABSMAX_SPLIT);
 }
 
 // compile-time loop and LDS instructions with immediate offsets (hand-placed: hipcc re-uses operand registers and then
@@ -758,6 +796,13 @@ int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int n
   }
   hipLaunchKernelGGL(split::conv3x3_relayout_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, Cin,
                      Cout, np, Cout <= 32 ? 1 : 2, total, reinterpret_cast<unsigned short*>(wr), dgrad);
+  return check_launch();
+}
+
+int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long long nblocks, int any_f16) {
+  if (njobs <= 0 || nblocks <= 0 || nblocks > 0x7fffffffLL || !jobs) return C2M_ERR_INVALID_ARG;
+  if (any_f16) hipLaunchKernelGGL(split::weight_absmax_multi_kernel, dim3((unsigned)njobs, split::ABSMAX_SPLIT), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(split::conv3x3_relayout_split_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs, njobs);
   return check_launch();
 }
 

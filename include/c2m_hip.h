@@ -260,6 +260,13 @@ size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout);  /* 0 if unsupported
 int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3, 1 or 2 (f16 x 2); 0 if unsupported (Cin % 16) */
 int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr);
+/* Many images per call (the per-forward refresh of a module's cached weight images from the parameters' current contents:
+ * ~160 tensors of a RestorationNet in two launches instead of three per tensor).  `jobs` = DEVICE array [njobs][8] of int64:
+ * {weight pointer, image pointer (sized by c2m_conv3x3_relayout_split_bytes), Cin, Cout, pieces | MT << 8 | dgrad << 16
+ * (MT = 1 for Cout <= 32 else 2), image bytes / 2 (without the f16 x 2 tail), first block (running sum of
+ * ceil(image elements / 256) over the jobs before), 0}; nblocks = that sum over all jobs; any_f16 != 0 if some job has
+ * pieces = 2 (then one more launch reduces max |w| of those tensors for their scales). */
+int c2m_conv3x3_relayout_split_multi(c2m_stream_t stream, const long long* jobs, int njobs, long long nblocks, int any_f16);
 int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* desc);
 
 /*

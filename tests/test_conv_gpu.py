@@ -469,6 +469,43 @@ def test_weight_cache_refresh_follows_data_writes(ops, dev):
         ops.refresh_weight_caches([w])
 
 
+def test_multi_tensor_refresh_equals_a_fresh_relayout(ops, dev):
+    """ops.refresh_weight_caches rebuilds all split-kernel images of its parameters in ONE multi-tensor call (device job
+    table): after `.data` writes the refreshed images must be bit-identical to images built from scratch -- every flavour
+    (bf16 x 3, f16 x 2 with its per-tensor scale, bf16), ragged cout blocks, a row-sliced DCN head, the data-gradient image."""
+    P = torch.nn.Parameter
+    w1, w2, w3 = P(_rand((64, 64, 3, 3), dev, 370, 0.05)), P(_rand((32, 48, 3, 3), dev, 371, 0.07)), P(_rand((256, 128, 3, 3), dev, 372, 0.03))
+    wh, bh = P(_rand((216, 64, 3, 3), dev, 373, 0.02)), _rand((216,), dev, 374, 0.1)
+    x1, x2, x3 = _cl(_rand((1, 64, 12, 40), dev, 375)), _cl(_rand((1, 48, 12, 40), dev, 376)), _cl(_rand((1, 128, 12, 40), dev, 377))
+    g1 = _cl(_rand((1, 64, 12, 40), dev, 378))
+    flow = torch.zeros(1, 10, 38, 2, device=dev)
+
+    def run():
+        outs = []
+        for algo in ("split", "split16", "bf16"):
+            outs += [ops.conv3x3(x1, w1, algo=algo), ops.conv3x3(x2, w2, algo=algo), ops.conv3x3(x3, w3, algo=algo)]
+        outs += list(ops.conv3x3_dcn_head(x1, wh, bh, 8, flow, 1, algo="split16"))
+        outs.append(ops.conv3x3_dgrad(g1, w1))
+        return outs
+
+    before = run()
+    for k, w in enumerate((w1, w2, w3, wh)):
+        w.data.mul_(1.7 + k).add_(_rand(tuple(w.shape), dev, 380 + k, 0.01))     # (no version bump)
+    assert ops.refresh_weight_caches([w1, w2, w3, wh]) >= 11
+    refreshed = run()
+    ops.clear_weight_caches()
+    fresh = run()
+    for a, b_, c in zip(before, refreshed, fresh):
+        assert torch.equal(b_, c)
+        assert not torch.equal(a, b_)
+    # a second round (same job table) after another write
+    w2.data.neg_()
+    ops.refresh_weight_caches([w1, w2, w3, wh])
+    again = ops.conv3x3(x2, w2, algo="split16")
+    ops.clear_weight_caches()
+    assert torch.equal(again, ops.conv3x3(x2, w2, algo="split16"))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # backward: data gradient (split kernel on rotated / transposed weights), weight gradient (csrc/conv3x3_wgrad.hip), the
 # autograd Function around them -- against float64 autograd of F.conv2d
