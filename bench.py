@@ -603,6 +603,20 @@ def main():
                 "exact-fp32-MFMA kernel at the tolerance of the other fp32 kernels (tests/test_conv_gpu.py: 1e-5 * scale); "
                 "$C2M_CONV_SPLIT16=0 runs the bf16 x 3 flavour (six products, full fp32 exponent range), $C2M_CONV_SPLIT=0 the "
                 "fp32-MFMA kernels -- `value_other_conv_arithmetic` times the same step with them")
+            try:   # measured, on this GPU, in this run: distance of every convolution arithmetic from a float64 convolution
+                g_ = torch.Generator(device=dev).manual_seed(77)
+                xe = torch.randn((1, 256, 24, 64), generator=g_, device=dev).contiguous(memory_format=torch.channels_last)
+                we = torch.randn((256, 256, 3, 3), generator=g_, device=dev) / 48.0
+                be = torch.randn((256,), generator=g_, device=dev)
+                want = torch.nn.functional.conv2d(xe.double(), we.double(), be.double(), padding=1)
+                chk = {"layer": "256 -> 256 channels, K = 2304, N(0,1) activations, outputs of magnitude ~5; error against float64 conv2d"}
+                from c2m_amd import ops as _o
+                for name, algo in (("fp32_mfma_direct", "direct"), ("f16x2_three_products", "split16"), ("bf16x3_six_products", "split")):
+                    d_ = (_o.conv3x3(xe, we, be, algo=algo).double() - want)
+                    chk[name] = {"max_abs": float(d_.abs().max()), "rms": float(d_.pow(2).mean().sqrt())}
+                line["conv_arithmetic_check"] = chk
+            except Exception as e:  # noqa: BLE001 -- a diagnostic, never the reason a bench line is lost
+                line["conv_arithmetic_check"] = {"error": repr(e)}
             if not args.no_alt:
                 # the same step on the other convolution arithmetics (outside the timed region of `value`)
                 from c2m_amd import ops as _ops

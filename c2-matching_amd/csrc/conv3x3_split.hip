@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                 if (more_in) issue_in_piece(std::integral_constant<int, R>());
               }
             }
-            if constexpr (!(ABL & 16)) {
+            if constexpr (!(ABL & 16) && !((ABL & 256) && dx == 2)) {   // (256: only two of the three taps' MFMAs -- what a Winograd F(2,3) would issue)
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -838,6 +838,7 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
         case 128: go(&split::conv3x3_split_kernel<NP, 2, 0, 128>, done_abl[10]); break;
         case 111: go(&split::conv3x3_split_kernel<NP, 2, 0, 111>, done_abl[11]); break;
         case 112: go(&split::conv3x3_split_kernel<NP, 2, 0, 112>, done_abl[12]); break;
+        case 256: go(&split::conv3x3_split_kernel<NP, 2, 0, 256>, done_abl[0]); break;
         default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL mask\n"); return C2M_ERR_INVALID_ARG;
       }
       return rc;
