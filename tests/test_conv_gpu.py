@@ -305,6 +305,8 @@ SPLIT_CASES = [c for c in CASES if c[2] % 4 == 0] + WINO_CASES + [   # (Cout = 3
     (1, [32], 64, 3, 5, 1, 0),           # map smaller than a tile
     (2, [48, 16], 96, 17, 33, 2, 1),     # 16-channel source boundary inside the stream, Cout = 64 + 32 (ragged cout block)
     (1, [64], 64, 64, 96, 1, 1),         # 24 tiles: several workgroups with several tiles each
+    (1, [32], 64, 384, 384, 1, 0),       # 576 tiles > 512 resident workgroups: persistent workgroups with TWO tiles each (the
+    (1, [16], 32, 384, 392, 2, 1),       # next tile's first chunk is split during the last chunk of this one); one-chunk tiles
 ]
 
 
