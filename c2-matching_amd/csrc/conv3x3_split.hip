@@ -1,41 +1,43 @@
-// conv3x3_split.hip -- 3x3 / stride 1 / pad 1 convolution, fp32 in / fp32 out, on the BF16 matrix pipe of gfx950 (MI355X).
+// conv3x3_split.hip -- 3x3 / stride 1 / pad 1 convolution, fp32 in / fp32 out, on the 16-BIT matrix pipe of gfx950 (MI355X).
 //
 // Same contract as conv3x3.hip (decoder stack ref_restoration_arch.py:140-187, arch_util.py:80-136,
 // DCN offset/mask head dcn_v2.py:229-245):   out = act( conv3x3( cat(src0, src1) ) + bias ) + res1 + res2
 // on channels-last fp32 tensors.  What changes is the arithmetic underneath.  On CDNA4 the fp32 MFMA
 // (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate (157 TF, and every VALU instruction next to it costs matrix
-// time); v_mfma_f32_32x32x16_bf16 is 16x faster and has its own pipe.  So every fp32 operand is split EXACTLY into three
-// bf16 pieces
+// time); v_mfma_f32_32x32x16_{f16,bf16} is 16x faster and has its own pipe.  Three flavours (template FL, struct Flavour):
+//   FL = 3  bf16 x 3: every fp32 operand split EXACTLY into three bf16 pieces
 //       x = x0 + x1 + x2,   x0 = top 16 bits of x,  x1 = top 16 bits of (x - x0),  x2 = x - x0 - x1   (8 + 8 + 8 mantissa bits)
-// and the product sum is taken over the six piece pairs whose magnitude is >= 2^-16 of the leading one,
+//     and the product sum taken over the six piece pairs whose magnitude is >= 2^-16 of the leading one,
 //       w.x ~= w0x0 + (w0x1 + w1x0) + (w1x1 + w0x2 + w2x0)            (dropped: w1x2, w2x1, w2x2 <= 2^-24 |w||x|)
-// accumulated in fp32 by the MFMA: 6/16 of the fp32-MFMA time for an error BELOW that of an fp32 fmaf chain (measured
-// on K = 576: 6e-8 of the result scale from the dropped terms against 5e-7 for fp32 accumulation itself).  NP = 1 keeps
-// only w0x0 with round-to-nearest pieces: the plain bf16 convolution of BASELINE configs[4] (bf16 inference), 1/6 of the
-// matrix work again.
+//     6/16 of the fp32-MFMA time, full fp32 exponent range: the arithmetic of the autograd path (forward + data gradient);
+//   FL = 2  f16 x 2: two round-to-nearest f16 pieces per activation (the low one stored times 2^11), weights scaled per tensor
+//     by a power of two and split the same way, THREE products (comment at struct Flavour): the inference default.  Error
+//     against float64 below the fp32-MFMA kernel's own (bench.py's conv_arithmetic_check); |x| < 65520, NaN beyond;
+//   FL = 1  bf16: one round-to-nearest piece, one product -- the plain bf16 convolution of BASELINE configs[4] (autocast).
+// All accumulate in fp32 in the MFMA.
 //
 // Mapping (one workgroup = 4 waves, TWO workgroups per CU = two waves per SIMD; 32 x 8 output pixels x MW = 32*MT couts):
 //   * wave w owns pixel rows 2w, 2w+1 of the tile: NT = 2 pixel tiles x MT channel tiles = 2*MT accumulators f32x16;
-//   * K is swept in chunks of 16 input channels (= K of one MFMA).  Per chunk, phase (A): the zero-padded 34 x 10 halo tile
-//     arrives as fp32 in REGISTERS (buffer_load_dwordx4 with hardware zero fill outside the image, issued a whole chunk
-//     ahead; 6 pieces per wave), every wave splits its pieces (22 VALU per 4 channels x pixel) into NP bf16 planes in LDS laid
-//     out [plane][k half][pixel][8 bf16]: a B operand (8 channels of one pixel) is one ds_read_b128, 16 consecutive lanes
-//     read 256 contiguous bytes for any tap shift (conflict-free without a swizzle).  The planes are single-buffered: while
-//     one workgroup splits, the co-resident one owns the matrix pipe;
-//   * phase (B): three units (kernel rows) of three taps.  Weights are split once per weight version on the host side of
-//     the call (conv3x3_relayout_split_kernel) into ready-made LDS images [cout block][chunk][dy][dx][plane][mt][k half]
-//     [32 rows][8 bf16]; a unit's image (3*NP*MT KiB) streams by LDS-DMA into a ring of 2 slots one unit ahead, its pieces
-//     issued one per MFMA group of the previous unit's first tap; one barrier per unit;
-//   * per tap: NP*MT A reads + NP*NT B reads (ds_read_b128, hand-placed: inline asm between sched_barrier fences, one tap
-//     ahead into the other of two register sets) feed NPROD*MT*NT MFMAs (24 for the fp32 flavour);
+//   * K is swept in chunks of 16 input channels (= K of one MFMA).  The zero-padded 34 x 10 halo tile of a chunk arrives as
+//     fp32 in REGISTERS (buffer_load_dwordx4 with hardware zero fill outside the image, issued a whole chunk or more
+//     ahead; 6 pieces per wave); every wave splits its pieces into NPX 16-bit planes in LDS laid out [plane][k half][pixel]
+//     [8 x 16 bit]: a B operand (8 channels of one pixel) is one ds_read_b128, 16 consecutive lanes read 256 contiguous bytes
+//     for any tap shift (conflict-free without a swizzle).  FL = 3: one plane buffer, the split is a phase (A) of its own
+//     (22 VALU per 4 channels x pixel) -- while one workgroup splits, the co-resident one owns the matrix pipe.  FL = 1, 2:
+//     two plane buffers, split round R of the NEXT chunk rides in the MFMA groups of taps 1, 2 of unit R / 2;
+//   * three units (kernel rows) of three taps per chunk.  Weights are split once per weight version on the host side of
+//     the call (conv3x3_relayout_split_kernel / _multi_kernel) into ready-made LDS images [cout block][chunk][dy][dx][image]
+//     [mt][k half][32 rows][8 x 16 bit]; a unit's image (3*NPW*MT KiB) streams by LDS-DMA into a ring of 2 (FL = 3) or 3
+//     slots, one or two units ahead, its pieces issued one per MFMA group of a unit's first tap; one barrier per unit;
+//   * per tap: NPW*MT A reads + NPX*NT B reads (ds_read_b128, hand-placed: inline asm between sched_barrier fences, one tap
+//     ahead into the other of two register sets) feed N*MT*NT MFMAs (24 for bf16 x 3, 12 for f16 x 2);
 //   * persistent tiles, XCD-aware tile order, epilogue in registers with the store flavours of conv3x3.hip (channels-last
 //     (+ residuals), PixelShuffle(2), planar NCHW, DCN offset/mask head) plus ReLU + MaxPool2d(2,2) (both rows of a
 //     pooling window live in one lane, the horizontal neighbour one lane over).
-// LDS: planes 36.75 KiB + weight ring 2 x 18 KiB + 1.25 KiB = 74 KiB (NP = 3, MT = 2); <= 256 registers.
-// How it got here: v1 LDS-DMA for halo and weights, one workgroup per CU (2.78 ms on the 64->64 @640^2 B=16
-// layer); v3 weights by per-wave buffer loads, halo through registers, two workgroups per CU (2.4-2.5 ms; the per-wave weight
-// loads quadrupled the L2 traffic); v4 (this file) weights once per workgroup through LDS again (2.3-2.4 ms, MFMA pipe 73 %
-// busy at the ~1.55 GHz the chip sustains under this load).
+// LDS (MT = 2): bf16 x 3: planes 31.9 KiB + ring 2 x 18 KiB + 1.25 KiB = 69 KiB; f16 x 2: planes 2 x 21.25 + ring 3 x 12 + 1.25 =
+// 79.75 KiB; <= 256 registers either way.
+// What bounds it: the chip's power budget -- the same instruction stream takes 1.58 ms on N(0,1) tensors
+// and 1.13 ms on zeros (64->64 @640^2, B = 16); history of the structure (v1 .. v5) and the ablation / A-B measurements there.
 #include <stdio.h>
 #include <stdlib.h>
 

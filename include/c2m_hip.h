@@ -56,7 +56,7 @@ int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device,
  */
 enum { C2M_KERNEL_CORR_MFMA = 1, C2M_KERNEL_CORR_GENERIC = 2, C2M_KERNEL_DCN_FWD = 3, C2M_KERNEL_DCN_BWD_DATA = 4,
        C2M_KERNEL_DCN_BWD_WEIGHT = 5, C2M_KERNEL_CONV3X3 = 6 /* fp32-MFMA direct / Winograd kernels */,
-       C2M_KERNEL_CONV3X3_SPLIT = 7 /* split-bf16 kernel (C2M_CONV_SPLIT_BF16X3 / C2M_CONV_BF16) */,
+       C2M_KERNEL_CONV3X3_SPLIT = 7 /* split kernel (C2M_CONV_SPLIT_F16X2 / C2M_CONV_SPLIT_BF16X3 / C2M_CONV_BF16) */,
        C2M_KERNEL_CONV3X3_WGRAD = 8 };
 enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LEAKY_RELU = 2 };   /* fused activations of the decoder-path entry points */
 int c2m_profile_enable(int on);
