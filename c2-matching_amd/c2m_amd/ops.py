@@ -330,6 +330,8 @@ class _WeightCache:
                     rowsl.append([wptr, iptr, ci, co, flags, elems, first, 0])
                     first += (elems + 255) // 256
                 tab = (sig, torch.tensor(rowsl, dtype=torch.int64).to(dev), first, int(any((j[4] & 0xff) == 2 for j in jobs)))
+                if len(self._tables) >= 64:      # (tables of parameter sets that no longer exist: a handful of KiB each)
+                    self._tables.clear()
                 self._tables[tkey] = tab
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib().c2m_conv3x3_relayout_split_multi(_stream(), tab[1].data_ptr(), len(jobs), tab[2], tab[3]),
