@@ -1,4 +1,4 @@
+# quick validation on one MI355X: smoke + the GPU test suite (the full measurement pass is scripts/gpu_final.sh)
 mkdir -p gpurun_out/quick
-O=gpurun_out/quick
-C2M_BENCH_FORCE_DIST=1 timeout 170 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_dist1.log 2>&1
-echo "rc=$?" >> $O/bench_dist1.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/quick/smoke.log 2>&1; tail -2 gpurun_out/quick/smoke.log
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/quick/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/quick/pytest_gpu.log | tail -3
