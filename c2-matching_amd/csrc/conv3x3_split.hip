@@ -868,7 +868,7 @@ int launch_split(hipStream_t st, Params p, int np) {
   static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
   const long long resident = 512;   // two workgroups per CU (75 KiB of LDS, <= 256 registers each)
   long long tpw = 1, best = -1;
-  for (long long t = 1; t <= 10; ++t) {
+  for (long long t = 1; t <= 16; ++t) {
     const long long wgs = ((ntile + t - 1) / t) * ncb;
     const long long cost = ((wgs + resident - 1) / resident) * t;
     if (best < 0 || cost <= best) { best = cost; tpw = t; }
