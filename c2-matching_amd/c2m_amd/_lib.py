@@ -50,6 +50,8 @@ def _declare(L):
     L.c2m_feature_match_workspace_bytes.argtypes = [_i] * 5
     L.c2m_feature_match_skip_table.argtypes = [_i] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     L.c2m_feature_match_index_f32.argtypes = [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp, _sz]
+    L.c2m_feature_match_set_filter.argtypes = [_i]
+    L.c2m_feature_match_filter_tables.argtypes = [_i] * 5 + [ctypes.POINTER(ctypes.c_size_t)] * 3 + [ctypes.POINTER(ctypes.c_int)]
     L.c2m_build_pre_offsets_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]
     for name in ("c2m_dcn_v2_forward_workspace_bytes",):
         getattr(L, name).restype = _sz
@@ -118,7 +120,8 @@ def device_arch():
 
 
 KERNEL_NAMES = {1: "corr_argmax_mfma", 2: "corr_argmax_generic", 3: "dcn_v2_forward", 4: "dcn_v2_backward_data",
-                5: "dcn_v2_backward_weight", 6: "conv3x3_mfma", 7: "conv3x3_split", 8: "conv3x3_wgrad"}
+                5: "dcn_v2_backward_weight", 6: "conv3x3_mfma", 7: "conv3x3_split", 8: "conv3x3_wgrad", 9: "corr_filter",
+                10: "corr_resolve"}
 
 
 def profile_enable(on=True):

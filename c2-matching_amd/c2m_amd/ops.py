@@ -69,6 +69,7 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
             table = _skip_table(ws, (B, Hq, Wq, Hr, Wr)) if mfma else None
             if _corr_diag.enabled:
                 _corr_diag.table = table
+                _corr_diag.filter = _filter_tables(ws, (B, Hq, Wq, Hr, Wr), Hqp * Wqp) if mfma else None
             if return_skip:
                 if table is None:
                     raise _lib.C2MError("return_skip: the duplicate-row table exists only on the MFMA kernel's path "
@@ -79,9 +80,11 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
 
 class _CorrDiag:
     """Opt-in diagnostics of the correlation launch: `with ops.record_corr_skip_table(): ...` keeps the duplicate-row table
-    of the most recent MFMA launch inside the block (a small int32 tensor, not the workspace)."""
+    of the most recent MFMA launch inside the block (a small int32 tensor, not the workspace) and the pre-filter's
+    candidate counts / flags."""
     enabled = False
     table = None
+    filter = None
 
 
 _corr_diag = _CorrDiag()
@@ -104,6 +107,42 @@ def _skip_table(ws, shp):
                "c2m_feature_match_skip_table")
     B = shp[0]
     return ws[off.value:off.value + 8 * B * nxt.value].view(torch.int32).view(B, nxt.value, 2).clone()
+
+
+def _filter_tables(ws, shp, nq):
+    import ctypes
+    c, k, f, slots = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().c2m_feature_match_filter_tables(*shp, ctypes.byref(c), ctypes.byref(k), ctypes.byref(f),
+                                                          ctypes.byref(slots)), "c2m_feature_match_filter_tables")
+    B, K = shp[0], slots.value
+    return {"cnt": ws[c.value:c.value + 4 * B * nq].view(torch.int32).view(B, nq).clone(),
+            "cand": ws[k.value:k.value + 4 * B * nq * K].view(torch.int32).view(B, nq, K).clone(),
+            "flags": ws[f.value:f.value + 32].view(torch.int32).clone()}
+
+
+def last_corr_filter_tables():
+    """Pre-filter diagnostics recorded under `record_corr_skip_table()`: {'cnt': int32 [B, Nq] candidates per query (-1 =
+    every ref patch re-scored), 'cand': int32 [B, Nq, slots], 'flags': int32 [8] ([0] != 0: the exact sweep produced the
+    result)} -- meaningful only if the most recent launch took the pre-filter path (c2m_feature_match_filter_tables)."""
+    if _corr_diag.filter is None:
+        raise _lib.C2MError("no MFMA correlation launch was recorded (use `with ops.record_corr_skip_table():`)")
+    return _corr_diag.filter
+
+
+class corr_filter_mode:
+    """`with ops.corr_filter_mode(0): ...` -- exact fp32 sweep only; (1): pre-filter + exact re-score (default); results are
+    identical (c2m_feature_match_set_filter).  Process-wide switch: measurement / tests, not for concurrent callers."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        _lib.check(_lib.lib().c2m_feature_match_set_filter(self.mode), "c2m_feature_match_set_filter")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.lib().c2m_feature_match_set_filter(-1), "c2m_feature_match_set_filter")
+        return False
 
 
 def last_corr_skip_table():

@@ -33,7 +33,10 @@
 // LDS: ring 3*256*32*4 = 96 KiB + row buffers 2*C*32*4 = 64 KiB (C=256) = all 160 KiB of a CU; 1 workgroup per CU,
 // 2 waves per SIMD.  Roofline: MFMA (fp32 matrix peak 157.3 TF); HBM traffic is a few times the compulsory 53 MB/pair
 // and <1 % of the HBM roofline.
+#include <stdlib.h>
+
 #include "c2m_common.h"
+#include "corr_filter.h"
 
 namespace c2m {
 
@@ -201,8 +204,12 @@ template <int C, bool DMA16>
 __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
     const float* __restrict__ fin, const float* __restrict__ fref, int Hq, int Wq, int Hr, int Wr, int tiles_y,
     int tiles_x, const float* __restrict__ inv, const float* __restrict__ qden, int is_norm, int norm_input,
-    const int2* __restrict__ skip, int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
+    const int2* __restrict__ skip, const int* __restrict__ need, int64_t* __restrict__ max_idx,
+    float* __restrict__ max_val) {
   using namespace corr;
+  // need != nullptr: this launch is the fall-back of the pre-filter path (corr_filter.hip) and runs only if the filter's
+  // preparation found inputs outside its domain (*need != 0); otherwise every workgroup returns at once
+  if (need != nullptr && *need == 0) return;
   constexpr int KP = C / 2;                    // MFMA k-pairs = resident A registers per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;                          // [3][QPIX][WT]
@@ -513,6 +520,7 @@ namespace {
 struct CorrWs {
   size_t ss_ref, inv, ss_in, qden, row_eq, skip, total;  // byte offsets
   int nxt;
+  c2m::corrf::Ws f;   // scratch of the pre-filter path (corr_filter.h)
 };
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
@@ -525,14 +533,15 @@ inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
   w.nxt = Wr > 2 ? (Wr - 2 + c2m::corr::WP - 1) / c2m::corr::WP : 1;
   w.row_eq = o; o = align256(o + sizeof(int) * (size_t)B * w.nxt * Hr);
   w.skip = o;   o = align256(o + sizeof(int2) * (size_t)B * w.nxt);
-  w.total = o;
+  w.f = c2m::corrf::workspace(o, B, Hq, Wq, Hr, Wr);
+  w.total = w.f.total;
   return w;
 }
 
 template <int C>
 int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B, int Hq, int Wq, int Hr, int Wr,
                      const float* inv, const float* qden, int* row_eq, int2* skip, int dedup, int64_t* max_idx,
-                     float* max_val) {
+                     float* max_val, const c2m::corrf::Ws* fws = nullptr, char* wsbase = nullptr, const float* qden_buf = nullptr) {
   using namespace c2m::corr;
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB + 2 * C * WT);
@@ -548,12 +557,42 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
     (void)hipMemsetAsync(row_eq, 0, sizeof(int) * (size_t)B * nxt * Hr, st);
   }
   hipLaunchKernelGGL(ref_row_run_kernel, dim3(ceil_div(B * nxt, 64)), dim3(64), 0, st, row_eq, Hr, B * nxt, skip);
+  const int* need = nullptr;
+  if (fws) {
+    // pre-filter + exact re-score; the sweep below then runs only if the filter's preparation raised its flag
+    if (int rc = c2m::corrf::launch(st, fin, fref, B, C, Hq, Wq, Hr, Wr, inv, qden_buf, qden ? 1 : 0, skip, wsbase, *fws, max_idx,
+                                    max_val))
+      return rc;
+    need = reinterpret_cast<const int*>(wsbase + fws->flags);
+  }
   ProfileScope prof(C2M_KERNEL_CORR_MFMA, st);
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, fin, fref, Hq, Wq, Hr, Wr, tiles_y, tiles_x, inv ? inv : fin,
-                     qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, skip, max_idx, max_val);
+                     qden ? qden : fin, inv ? 1 : 0, qden ? 1 : 0, skip, need, max_idx, max_val);
   return check_launch();
 }
 }  // namespace
+
+namespace {
+int g_filter_mode = -1;   // -1: $C2M_CORR_FILTER (default on), 0 / 1: forced by c2m_feature_match_set_filter
+}
+
+extern "C" int c2m_feature_match_set_filter(int mode) {
+  if (mode < -1 || mode > 1) return C2M_ERR_INVALID_ARG;
+  g_filter_mode = mode;
+  return C2M_OK;
+}
+
+extern "C" int c2m_feature_match_filter_tables(int B, int Hq, int Wq, int Hr, int Wr, size_t* cnt_offset, size_t* cand_offset,
+                                               size_t* flags_offset, int* slots) {
+  if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0 || !cnt_offset || !cand_offset || !flags_offset || !slots)
+    return C2M_ERR_INVALID_ARG;
+  const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr);
+  *cnt_offset = ws.f.cnt;
+  *cand_offset = ws.f.cand;
+  *flags_offset = ws.f.flags;
+  *slots = c2m::corrf::KSLOT;
+  return C2M_OK;
+}
 
 extern "C" size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr) {
   if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0) return 0;
@@ -595,7 +634,17 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
                        ref_stride, Hrp, Wrp, 1, inv);
     if ((rc = check_launch()) != C2M_OK) return rc;
   }
-  if (norm_input) {
+  const bool fast = !force_generic && patch == 3 && in_stride == 1 && ref_stride == 1 &&
+                    (C == 64 || C == 128 || C == 256);
+  // The pre-filter path (corr_filter.hip): 3/16 of the matrix time, same results.  It needs the ref-patch normalisation
+  // (its error bound is relative to |r|) and shapes its 16-bit candidate codes cover.  $C2M_CORR_FILTER=0: exact sweep only.
+  static const int filter_env = [] {
+    const char* e = getenv("C2M_CORR_FILTER");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  const int filter_on = g_filter_mode < 0 ? filter_env : g_filter_mode;
+  const bool use_filter = fast && filter_on && is_norm && c2m::corrf::shapes_ok(B, C, Hq, Wq, Hr, Wr);
+  if (norm_input || use_filter) {
     hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hq * Wq, 256), B), dim3(256), 0, st, feat_in, C, Hq * Wq,
                        ss_in);
     hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hqp * Wqp, 256), B), dim3(256), 0, st, ss_in, Hq, Wq, patch,
@@ -605,23 +654,22 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
   const float* invp = is_norm ? inv : nullptr;
   const float* qdp = norm_input ? qden : nullptr;
 
-  const bool fast = !force_generic && patch == 3 && in_stride == 1 && ref_stride == 1 &&
-                    (C == 64 || C == 128 || C == 256);
   if (fast) {
     int* row_eq = reinterpret_cast<int*>(wsb + ws.row_eq);
     int2* skip = reinterpret_cast<int2*>(wsb + ws.skip);
+    const c2m::corrf::Ws* fwsp = use_filter ? &ws.f : nullptr;
     static const int dedup = [] {
       const char* e = getenv("C2M_CORR_DEDUP");  // 0: score every ref row (measurement / debugging)
       return (e && e[0] == '0') ? 0 : 1;
     }();
     if (C == 256)
       return launch_corr_mfma<256>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
-                                   max_val);
+                                   max_val, fwsp, wsb, qden);
     if (C == 128)
       return launch_corr_mfma<128>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
-                                   max_val);
+                                   max_val, fwsp, wsb, qden);
     return launch_corr_mfma<64>(st, feat_in, feat_ref, B, Hq, Wq, Hr, Wr, invp, qdp, row_eq, skip, dedup, max_idx,
-                                max_val);
+                                max_val, fwsp, wsb, qden);
   }
   const size_t lds = sizeof(float) * (size_t)patch * patch * C;
   if (lds > 60 * 1024) return C2M_ERR_UNSUPPORTED;

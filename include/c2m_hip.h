@@ -57,7 +57,9 @@ int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device,
 enum { C2M_KERNEL_CORR_MFMA = 1, C2M_KERNEL_CORR_GENERIC = 2, C2M_KERNEL_DCN_FWD = 3, C2M_KERNEL_DCN_BWD_DATA = 4,
        C2M_KERNEL_DCN_BWD_WEIGHT = 5, C2M_KERNEL_CONV3X3 = 6 /* fp32-MFMA direct / Winograd kernels */,
        C2M_KERNEL_CONV3X3_SPLIT = 7 /* split kernel (C2M_CONV_SPLIT_F16X2 / C2M_CONV_SPLIT_BF16X3 / C2M_CONV_BF16) */,
-       C2M_KERNEL_CONV3X3_WGRAD = 8 };
+       C2M_KERNEL_CONV3X3_WGRAD = 8,
+       C2M_KERNEL_CORR_FILTER = 9 /* f16-pipe pre-filter sweep of the correlation (corr_filter.hip) */,
+       C2M_KERNEL_CORR_RESOLVE = 10 /* exact fp32 re-score of the filter's candidates */ };
 enum { C2M_ACT_NONE = 0, C2M_ACT_RELU = 1, C2M_ACT_LEAKY_RELU = 2 };   /* fused activations of the decoder-path entry points */
 int c2m_profile_enable(int on);
 int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
@@ -69,7 +71,8 @@ int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
 /* x, out: [B][C][HW] fp32.  out[b,c,p] = x[b,c,p] / max(||x[b,:,p]||_2, 1e-12).  In-place allowed. */
 int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out);
 
-/* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps, duplicate-row table). */
+/* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps, duplicate-row table, and
+ * the pre-filter's channels-last copies / f16 pieces / candidate lists, sized for C = 256). */
 size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr);
 
 /*
@@ -79,6 +82,28 @@ size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr);
  * tie rule of ref_map_util.py:74).  from == to: every row swept.  $C2M_CORR_DEDUP=0 disables the elimination.
  */
 int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* byte_offset, int* x_tiles);
+
+/*
+ * The MFMA path of c2m_feature_match_index_f32 has two implementations with identical results (indices AND values):
+ *   exact sweep   every (query, ref patch) score on the fp32 matrix pipe (corr_argmax.hip);
+ *   pre-filter    the same sweep on the f16 matrix pipe (two pieces per operand, three products: 3/16 of the matrix time)
+ *                 keeps, per query, every candidate whose filter score lies within a RIGOROUS error band of the best one
+ *                 (8.4e-5 |query patch| + 1e-6); the listed candidates are then re-scored with the oracle's exact fp32
+ *                 chain and the first maximum taken (corr_filter.hip).  Needs is_norm, |x| < 3.99 everywhere and ref patch
+ *                 norms >= 0.5 (channel-normalised features satisfy all three); anything else falls back to the exact
+ *                 sweep on the device, without a host round trip.
+ * mode: 1 pre-filter (default), 0 exact sweep only, -1 follow $C2M_CORR_FILTER (unset = 1).  Process-wide.
+ */
+int c2m_feature_match_set_filter(int mode);
+
+/*
+ * Diagnostics of the pre-filter: after c2m_feature_match_index_f32 took that path the workspace holds int32 [B][Hqp*Wqp]
+ * candidate counts at *cnt_offset (-1 = every ref patch was re-scored), int32 [B][Hqp*Wqp][*slots] candidates at
+ * *cand_offset (>= 0x40000000: "re-score the whole candidate set of lane (entry & 31)") and int32 flags at *flags_offset
+ * ([0] != 0: the inputs were outside the filter's domain and the exact sweep produced the result).
+ */
+int c2m_feature_match_filter_tables(int B, int Hq, int Wq, int Hr, int Wr, size_t* cnt_offset, size_t* cand_offset,
+                                    size_t* flags_offset, int* slots);
 
 /*
  * feat_in [B][C][Hq][Wq], feat_ref [B][C][Hr][Wr] fp32 contiguous; for every sample b independently
