@@ -1,0 +1,43 @@
+#!/bin/bash
+# One parametrised GPU lease script (replaces the per-experiment scripts of earlier rounds):
+#   gpurun --timeout N -- 'bash scripts/gpu_run.sh <tag> <stage> [<stage> ...]'
+# Stages write under gpurun_out/<tag>/.  Everything DESIGN.md / profiles/ quote comes from `final`.
+set -x
+TAG=$1; shift
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+for stage in "$@"; do
+  case $stage in
+    smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ;;
+    test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
+    test_conv)  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_conv.log ;;
+    test_dcn)   timeout 900 python -m pytest tests/test_dcn_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_dcn.log ;;
+    test_rest)  timeout 1500 python -m pytest tests/test_restoration_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_restoration.log ;;
+    test_all)   timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | tail -220 > $O/pytest_gpu.log ;;
+    diag_corr)  timeout 600 python scripts/diag_corr_filter.py --lr320 > $O/diag_corr_filter.log 2>&1 ;;
+    bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; echo "rc=$?" >> $O/bench_default.log ;;
+    bench_quick) timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_quick.log 2>&1; echo "rc=$?" >> $O/bench_quick.log ;;
+    bench_corr) timeout 300 python bench.py --workload corr --steps 10 --warmup 3 > $O/bench_corr.log 2>&1 ;;
+    bench_train) timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.log 2>&1
+                C2M_TRAIN_KERNELS=1 timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train_kernels.log 2>&1
+                C2M_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload train --steps 10 --warmup 3 > $O/bench_train_rccl_1rank.log 2>&1 ;;
+    bench_cfg5) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 > $O/bench_cfg5_bf16.log 2>&1
+                timeout 300 python bench.py --lr 320 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_f32.log 2>&1 ;;
+    bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
+    bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;
+    prof)       cd /tmp
+                timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_step -o step -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_step.log 2>&1
+                cd $R ;;
+    pmc)        cd /tmp
+                timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace -f csv -d $O/pmc_mfma -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_mfma.log 2>&1
+                timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_fetch.log 2>&1
+                timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_write.log 2>&1
+                cd $R ;;
+    *)          echo "unknown stage $stage" ;;
+  esac
+done
+cd $R
+find gpurun_out/$TAG -name "*.db" -delete
+find gpurun_out/$TAG -name "*kernel_trace.csv" -size +8M -delete

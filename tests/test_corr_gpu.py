@@ -278,3 +278,83 @@ def test_mmsr_ref_map_util_signature(env, dev):
     p = sample_patches(_t(fr, dev), 3, 1)
     assert tuple(p.shape) == (256, 3, 3, 12 * 9)
     assert torch.equal(p[:, 1, 2, 9 + 4], _t(fr, dev)[:, 1 + 1, 4 + 2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the two implementations of the MFMA path: f16-pipe pre-filter + exact re-score (default) and the exact fp32 sweep
+# ---------------------------------------------------------------------------------------------------------------------
+def _both_modes(ops, fi, fr, **kw):
+    out = {}
+    for mode in (1, 0):
+        with ops.corr_filter_mode(mode), ops.record_corr_skip_table():
+            idx, val = ops.feature_match_index_batched(fi, fr, 3, 1, 1, True, True, **kw)
+            out[mode] = (idx.cpu().numpy(), val.cpu().numpy(), ops.last_corr_filter_tables())
+    return out
+
+
+@pytest.mark.parametrize("C,hq,hr,B", [(256, (40, 40), (40, 40), 3), (128, (33, 47), (52, 41), 2), (64, (20, 75), (61, 30), 2),
+                                        (256, (16, 16), (90, 90), 1)])
+def test_prefilter_equals_exact_sweep(env, dev, C, hq, hr, B):
+    """Same index maps and values, bit for bit, from the pre-filter path and from the exact sweep; the pre-filter really
+    produced its result (no domain fall-back) from short candidate lists that contain the arg-max."""
+    ops, oracle, synth = env
+    fi = np.stack([oracle.feature_normalize(synth.gaussish((C,) + hq, 300 + b)) for b in range(B)])
+    fr = np.stack([oracle.feature_normalize(synth.gaussish((C,) + hr, 400 + b)) for b in range(B)])
+    fr[0, :, hr[0] // 2:, :] = fr[0, :, hr[0] // 2:hr[0] // 2 + 1, :]      # a band of identical rows in sample 0
+    r = _both_modes(ops, _t(fi, dev), _t(fr, dev))
+    assert np.array_equal(r[1][0], r[0][0]) and np.array_equal(r[1][1], r[0][1])
+    tab = r[1][2]
+    assert int(tab["flags"][0]) == 0, "the pre-filter fell back to the exact sweep on in-domain inputs"
+    cnt = tab["cnt"].cpu().numpy()
+    assert cnt.min() >= 1 and np.mean(cnt == 1) > 0.8, np.bincount(cnt.ravel() + 1)
+    cand = tab["cand"].cpu().numpy()
+    one = cnt == 1
+    assert np.array_equal(cand[..., 0][one], r[1][0].reshape(B, -1)[one])      # a single candidate IS the answer
+    for b in range(B):
+        oi, ov = oracle.feature_match_index(fi[b], fr[b], 3, 1, 1, True, True)
+        assert np.array_equal(r[1][0][b], oi) and np.array_equal(r[1][1][b], ov)
+
+
+def test_prefilter_leaves_its_domain_through_the_exact_sweep(env, dev):
+    """|x| >= 3.99 (f16 pieces would overflow), a degenerate all-zero ref patch (1 / (|r| + 1e-5) > 2) and a NaN each raise the
+    device flag; the result is then the exact sweep's -- the oracle's -- without a host round trip."""
+    ops, oracle, synth = env
+    base_i = oracle.feature_normalize(synth.gaussish((256, 24, 24), 11))
+    base_r = oracle.feature_normalize(synth.gaussish((256, 30, 30), 12))
+    big = base_r.copy(); big[7, 5, 9] = 6.0
+    zero = base_r.copy(); zero[:, 10:14, 3:7] = 0.0
+    for name, fr in (("large value", big), ("zero patch", zero)):
+        with ops.record_corr_skip_table():
+            idx, val = ops.feature_match_index_batched(_t(base_i[None], dev), _t(fr[None], dev), 3, 1, 1, True, True)
+            flags = ops.last_corr_filter_tables()["flags"]
+        assert int(flags[0]) != 0, name
+        oi, ov = oracle.feature_match_index(base_i, fr, 3, 1, 1, True, True)
+        assert np.array_equal(idx[0].cpu().numpy(), oi) and np.array_equal(val[0].cpu().numpy(), ov), name
+
+
+def test_exact_sweep_alone_still_matches_the_oracle(env, dev):
+    ops, oracle, synth = env
+    fi = oracle.feature_normalize(synth.gaussish((256, 31, 29), 21))
+    fr = oracle.feature_normalize(synth.gaussish((256, 40, 59), 22))
+    fr[:, :, 30:] = fr[:, :, 1:30]   # exact ties
+    with ops.corr_filter_mode(0):
+        gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr)
+    assert np.array_equal(gi, oi) and np.array_equal(gv, ov)
+
+
+def test_prefilter_near_ties_are_resolved_exactly(env, dev):
+    """Ref patches that differ from another one by a few ulps of a few channels: their filter scores fall inside the band, the
+    listed candidates are re-scored with the oracle's chain and the oracle's pick comes out (value included)."""
+    ops, oracle, synth = env
+    fi = oracle.feature_normalize(synth.gaussish((256, 22, 22), 31))
+    fr = oracle.feature_normalize(synth.gaussish((256, 26, 52), 32))
+    right = fr[:, :, :26].copy()
+    rs = np.random.RandomState(5)
+    mask = rs.rand(*right.shape) < 0.02
+    right[mask] = np.nextafter(right[mask], np.float32(1.0))   # one ulp up on 2 % of the elements
+    fr[:, :, 26:] = right
+    with ops.record_corr_skip_table():
+        gi, gv, oi, ov = _run_case(ops, oracle, dev, fi, fr)
+        tab = ops.last_corr_filter_tables()
+    assert np.array_equal(gi, oi) and np.array_equal(gv, ov)
+    assert int(tab["flags"][0]) == 0 and float((tab["cnt"] >= 2).float().mean()) > 0.5   # the near-twins were both listed
