@@ -152,6 +152,23 @@ def corr_roofline(B, C, h, kms, n, pmc, swept=None):
                                          "of a 500x500 Ref) are not swept: exact, data-dependent (no such rows -> full sweep)"}
 
 
+def corr_filter_roofline(B, C, h, kern, pmc, swept=None):
+    """The correlation on its default path (csrc/corr_filter.hip): the sliding-window sweep on the f16 matrix pipe (three piece
+    products per k step: 3 * C/16 MFMAs of 32x32x16 per wave and ref row) + the exact fp32 re-score of the listed candidates."""
+    fk, rk = kern.get("corr_filter", []), kern.get("corr_resolve", [])
+    fms = sum(fk) / max(len(fk), 1)
+    tiles = ((h - 2 + 13) // 14) ** 2
+    rows = swept[0] if swept else B * ((h - 2 + 27) // 28) * h
+    execd = tiles * (rows + B) * 8 * (3 * C // 16) * (2 * 32 * 32 * 16)
+    algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9
+    return {"bound": "mfma", "pipe": "f16 MFMA", "kernel": f"corr_filter_kernel<{C}> (+ corr_resolve_kernel: exact fp32 re-score)",
+            "achieved": _tf(execd, fms), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(execd, fms) / BF16_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc.get("corr_filter_hbm_bytes_per_launch"), "kernel_ms": fms, "launches_timed": len(fk),
+            "resolve_ms": sum(rk) / max(len(rk), 1), "executed_flops_per_launch": execd, "algorithmic_flops_per_launch": algo,
+            "algorithmic_equiv_tflops": _tf(algo, fms + sum(rk) / max(len(rk), 1)),
+            "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None}
+
+
 def dcn_roofline(name, B, C, Co, H, kms, n, traffic=None, src=None):
     flops = B * 2.0 * Co * 9 * C * H * H                     # SURVEY.md 8d: 2*Co*(9C)*H*W per sample (executed = algorithmic)
     return {"bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": _tf(flops, kms),
@@ -511,12 +528,15 @@ def main():
         assert int(out[0].min()) >= 0 and int(out[0].max()) < (h - 2) ** 2
         swept = corr_swept_rows(h)
         ck = kern.get("corr_argmax_mfma", [])
+        filt = bool(kern.get("corr_filter"))
         line = dict(base, metric=METRIC + " -- correlation + index map only", value=B * world * args.steps / dt,
                     ms_per_step=dt / args.steps * 1e3, dtype="f32",
                     config={"workload": f"configs[1]: batch-{B} {h}x{h} LR / 500x500 Ref (zero-padded to {4*h}), feature "
                                         "normalise + 3x3 correlation/arg-max index map + pre-offset maps (NO DCNv2 / decoder)",
                             "feature_channels": C, "parallelism": f"dp{world} (batch-sharded, no collective)"},
-                    roofline=corr_roofline(B, C, h, sum(ck) / max(len(ck), 1), len(ck), pmc, swept))
+                    roofline=corr_filter_roofline(B, C, h, kern, pmc, swept) if filt else
+                    corr_roofline(B, C, h, sum(ck) / max(len(ck), 1), len(ck), pmc, swept))
+        line["c2m_kernel_ms_per_step"] = {k: round(sum(v) / args.steps, 4) for k, v in kern.items()}
         if world == 1 and not args.no_cpu_baseline and rank == 0:
             line["cpu_baseline"] = cpu_baseline_corr(h, C)
         return finish(line)
@@ -567,7 +587,9 @@ def main():
     if rank == 0:
         rl = []
         ck = kern.get("corr_argmax_mfma", [])
-        if ck:
+        if kern.get("corr_filter"):
+            rl.append(corr_filter_roofline(B, C, h, kern, pmc, swept))
+        elif ck:
             rl.append(corr_roofline(B, C, h, sum(ck) / len(ck), len(ck), pmc, swept))
         dk = kern.get("dcn_v2_forward", [])
         layers = (("small", 256, h), ("medium", 128, 2 * h), ("large", 64, 4 * h))

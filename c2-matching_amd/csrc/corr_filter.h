@@ -10,6 +10,7 @@ namespace corrf {
 
 constexpr int WP = 28;       // ref patches per x-tile (as the exact kernel)
 constexpr int KSLOT = 8;     // candidate slots per query handed from the filter to the re-score kernel
+constexpr int SCAN_ITEMS = 8192;   // capacity of the re-score work list
 constexpr int CMAX = 256;    // the workspace is sized for the widest feature map the filter serves
 
 // byte offsets of the filter's scratch inside the correlation workspace (relative to `base`)
@@ -22,7 +23,9 @@ struct Ws {
   size_t eq;            // uint8 [2][B][Hr*Wr]: pixel == left neighbour / == upper neighbour (all channels, bitwise)
   size_t cnt;           // int   [B][Hqp*Wqp]: candidates per query (-1: score every ref patch)
   size_t cand;          // int   [B][Hqp*Wqp][KSLOT]
-  size_t flags;         // int   [8]: [0] != 0 -> the exact sweep must run (inputs outside the filter's domain)
+  size_t flags;         // int   [8]: [0] != 0 -> the exact sweep must run (inputs outside the filter's domain); [1] work-list length
+  size_t keys;          // u64   [B][Hqp*Wqp]: running best (order-preserving value bits, ~index) of queries on the work list
+  size_t items;         // {int64 query, int lane, int pad} [SCAN_ITEMS]: whole-lane / whole-map re-score requests
   size_t total;
 };
 
@@ -45,6 +48,8 @@ inline Ws workspace(size_t base, int B, int Hq, int Wq, int Hr, int Wr) {
   w.cnt = o;   o = al256(o + nqp * 4);
   w.cand = o;  o = al256(o + nqp * 4 * KSLOT);
   w.flags = o; o = al256(o + 32);
+  w.keys = o;  o = al256(o + nqp * 8);
+  w.items = o; o = al256(o + (size_t)SCAN_ITEMS * 16);
   w.total = o;
   return w;
 }

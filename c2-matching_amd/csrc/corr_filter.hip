@@ -34,6 +34,8 @@
 // 1.3 % more (profiles/r04_corr_band_histogram_lr160.json); measured |F - R| is 3.5e-7.
 #include "corr_filter.h"
 
+#include <stdlib.h>
+
 #include "c2m_common.h"
 
 namespace c2m {
@@ -45,6 +47,8 @@ constexpr float PIECE_SCALE = 16384.0f;                 // 2^14: both maps are s
 constexpr float SCORE_UNSCALE = 3.725290298461914e-9f;  // 2^-28, folded into the candidate scales
 constexpr float F16_MIN_NORMAL = 6.103515625e-5f;   // 2^-14
 constexpr int SCAN_FLAG = 0x40000000;
+constexpr int SCAN_CAP = SCAN_ITEMS;           // work-list entries (whole-lane / whole-map re-scores); more: exact sweep
+constexpr int SCAN_CHUNKS = 32, SCAN_STRIPES = 64;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -204,7 +208,7 @@ __device__ __forceinline__ unsigned select_u32(unsigned long long lane_mask, uns
   return r;
 }
 
-template <int C>
+template <int C, int PF>
 __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     const _Float16* __restrict__ qpl, const _Float16* __restrict__ rimg, int Hq, int Wq, int Hr, int Wr, int tiles_y, int tiles_x,
     const float* __restrict__ sc, const float* __restrict__ band, const int2* __restrict__ skip, int* __restrict__ cnt,
@@ -313,23 +317,26 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const unsigned cur = code, curhi = code << 16;
 
-    // B operands: read one k step ahead into the other of two register sets
-    f16x8 b0[2], b1[2];
+    // B operands: read PF k steps ahead into a ring of PF + 1 register sets
+    f16x8 b0[PF + 1], b1[PF + 1];
     float hq[3];
-    b0[0] = *reinterpret_cast<const f16x8*>(bsrc);
-    b1[0] = *reinterpret_cast<const f16x8*>(bsrc + KS * 1024);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      b0[t] = *reinterpret_cast<const f16x8*>(bsrc + t * 1024);
+      b1[t] = *reinterpret_cast<const f16x8*>(bsrc + (KS + t) * 1024);
+    }
     hq[0] = a0[0]; hq[1] = a1[0]; hq[2] = a2[0];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[1][t], b0[t & 1], acc, 0, 0, 0);   // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[1][t], b0[t % (PF + 1)], acc, 0, 0, 0);   // smallest terms first
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < KS) {
-        b0[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(bsrc + (t + 1) * 1024);
-        b1[(t + 1) & 1] = *reinterpret_cast<const f16x8*>(bsrc + (KS + t + 1) * 1024);
+      if (t + PF < KS) {
+        b0[(t + PF) % (PF + 1)] = *reinterpret_cast<const f16x8*>(bsrc + (t + PF) * 1024);
+        b1[(t + PF) % (PF + 1)] = *reinterpret_cast<const f16x8*>(bsrc + (KS + t + PF) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b1[t & 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b0[t & 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b1[t % (PF + 1)], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b0[t % (PF + 1)], acc, 0, 0, 0);
       // tap-sum rounds [t NIT / KS, (t+1) NIT / KS)
 #pragma unroll
       for (int r = t * NIT / KS; r < (t + 1) * NIT / KS; ++r) {
@@ -415,32 +422,39 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// exact re-score: nine lanes per query (lane = tap), seven queries per wave
+// exact re-score.  Nine lanes per candidate (lane = tap (ti, tj): a sequential fmaf chain over the channels of query pixel
+// q + (ti, tj) and ref pixel n + (ti, tj), channels-last copies), seven candidates per wave; the nine taps are exchanged
+// inside the group and summed in the oracle's order.
+//   corr_resolve_kernel      one group per query: its listed candidates.  Requests to re-score a whole lane's candidate set
+//                            (or every ref patch) go to a work list instead; the query's running best is parked as a 64-bit
+//                            key (value bits made order-preserving, then ~index: atomicMax = larger value, then lower index)
+//   corr_scan_kernel         the work list, spread over a fixed grid (chunk, stripe): atomicMax into the query's key
+//   corr_scan_finish_kernel  keys of the listed queries -> max_idx / max_val
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) corr_resolve_kernel(const float* __restrict__ qn, const float* __restrict__ rn, int C, int Hq,
-                                                            int Wq, int Hr, int Wr, const float* __restrict__ inv,
-                                                            const float* __restrict__ qden, int norm_input,
-                                                            const int* __restrict__ cnt, const int* __restrict__ cand,
-                                                            long long nq_total, int64_t* __restrict__ max_idx,
-                                                            float* __restrict__ max_val) {
-  const int l = threadIdx.x & 63, grp = l / 9, tap = l - grp * 9;
-  const int gbase = grp * 9;
-  const long long q = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 7 + grp;
-  if (grp >= 7 || q >= nq_total) return;
-  const int Hqp = Hq - 2, Wqp = Wq - 2, Hrp = Hr - 2, Wrp = Wr - 2, Nq = Hqp * Wqp, Nr = Hrp * Wrp;
-  const int b = (int)(q / Nq), qq = (int)(q - (long long)b * Nq);
-  const int qy = qq / Wqp, qxx = qq - qy * Wqp;
-  const int ti = tap / 3, tj = tap - ti * 3;
-  const f32x4* qp = reinterpret_cast<const f32x4*>(qn + (((size_t)b * Hq + qy + ti) * Wq + qxx + tj) * C);
-  const float* rb = rn + (size_t)b * Hr * Wr * C;
-  const float* invb = inv + (size_t)b * Nr;
-  float best = -INFINITY;
-  int bidx = 0x7fffffff;
-  auto score = [&](int n) __attribute__((always_inline)) {
+struct ScanItem { long long q; int lane; int pad; };   // lane < 0: every ref patch
+
+__device__ __forceinline__ unsigned long long pack_key(float v, int n) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)n);
+}
+__device__ __forceinline__ void unpack_key(unsigned long long k, float& v, int& n) {
+  const unsigned ord = (unsigned)(k >> 32);
+  v = __builtin_bit_cast(float, (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+  n = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+}
+
+struct ExactScorer {
+  const f32x4* qp;      // this lane's query pixel
+  const float* rb;      // ref map of the sample (channels-last)
+  const float* invb;
+  int C4, Wr, Wrp, ti, tj, gbase;
+  __device__ __forceinline__ float operator()(int n) const {
     const int ry = n / Wrp, rx = n - ry * Wrp;
-    const f32x4* rp = reinterpret_cast<const f32x4*>(rb + ((size_t)(ry + ti) * Wr + rx + tj) * C);
+    const f32x4* rp = reinterpret_cast<const f32x4*>(rb + ((size_t)(ry + ti) * Wr + rx + tj) * (size_t)(4 * C4));
     float d = 0.0f;
-    for (int c4 = 0; c4 < C / 4; ++c4) {
+#pragma unroll 8
+    for (int c4 = 0; c4 < C4; ++c4) {   // (the loads of eight iterations are in flight together; the chain itself is sequential)
       const f32x4 a = qp[c4], r = rp[c4];
       d = __builtin_fmaf(a[0], r[0], d);
       d = __builtin_fmaf(a[1], r[1], d);
@@ -453,29 +467,113 @@ __global__ void __launch_bounds__(256) corr_resolve_kernel(const float* __restri
     const float r0 = t[0] + (t[1] + t[2]), r1 = t[3] + (t[4] + t[5]), r2 = t[6] + (t[7] + t[8]);
     float sum = r0 + r1;
     sum = sum + r2;
-    const float v = sum * invb[n];
-    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+    return sum * invb[n];
+  }
+};
+
+__device__ __forceinline__ ExactScorer make_scorer(const float* qn, const float* rn, const float* inv, int C, int Hq, int Wq, int Hr,
+                                                   int Wr, long long q, int tap, int gbase) {
+  const int Hqp = Hq - 2, Wqp = Wq - 2, Nq = Hqp * Wqp, Nr = (Hr - 2) * (Wr - 2);
+  const int b = (int)(q / Nq), qq = (int)(q - (long long)b * Nq);
+  const int qy = qq / Wqp, qxx = qq - qy * Wqp;
+  ExactScorer s;
+  s.ti = tap / 3;
+  s.tj = tap - s.ti * 3;
+  s.qp = reinterpret_cast<const f32x4*>(qn + (((size_t)b * Hq + qy + s.ti) * Wq + qxx + s.tj) * C);
+  s.rb = rn + (size_t)b * Hr * Wr * C;
+  s.invb = inv + (size_t)b * Nr;
+  s.C4 = C / 4; s.Wr = Wr; s.Wrp = Wr - 2; s.gbase = gbase;
+  return s;
+}
+
+__global__ void __launch_bounds__(256) corr_resolve_kernel(const float* __restrict__ qn, const float* __restrict__ rn, int C, int Hq,
+                                                            int Wq, int Hr, int Wr, const float* __restrict__ inv,
+                                                            const float* __restrict__ qden, int norm_input,
+                                                            const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                            long long nq_total, unsigned long long* __restrict__ keys,
+                                                            ScanItem* __restrict__ items, int* __restrict__ flags,
+                                                            int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
+  const int l = threadIdx.x & 63, grp = l / 9, tap = l - grp * 9;
+  const long long q = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 7 + grp;
+  if (grp >= 7 || q >= nq_total) return;
+  const int Nr = (Hr - 2) * (Wr - 2);
+  const ExactScorer score = make_scorer(qn, rn, inv, C, Hq, Wq, Hr, Wr, q, tap, grp * 9);
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  bool deferred = false;
+  auto defer = [&](int lane) __attribute__((always_inline)) {
+    if (tap == 0) {
+      const int slot = atomicAdd(&flags[1], 1);
+      if (slot < SCAN_CAP) items[slot] = ScanItem{q, lane, 0};
+      else flags[0] = 1;   // work list full: the exact sweep takes over
+    }
+    deferred = true;
   };
   const int c = cnt[q];
   if (c >= 0) {
     for (int e = 0; e < c; ++e) {
       const int ent = cand[q * KSLOT + e];
       if (ent & SCAN_FLAG) {
-        const int jl = ent & 31;
-        for (int col = jl; col < Wrp; col += WP)
-          if (jl < WP)
-            for (int ry = 0; ry < Hrp; ++ry) score(ry * Wrp + col);
+        defer(ent & 31);
       } else if (ent < Nr) {
-        score(ent);
+        const float v = score(ent);
+        if (v > best || (v == best && ent < bidx)) { best = v; bidx = ent; }
       }
     }
   } else {
-    for (int n = 0; n < Nr; ++n) score(n);
+    defer(-1);
   }
   if (tap == 0) {
-    float v = best;
+    if (deferred) {
+      keys[q] = pack_key(best, bidx);
+    } else {
+      float v = best;
+      if (norm_input) v = v / qden[q];
+      max_idx[q] = (int64_t)bidx;
+      max_val[q] = v;
+    }
+  }
+}
+
+// grid (SCAN_CHUNKS, SCAN_STRIPES): item = stripe, stripe + SCAN_STRIPES, ...; inside an item, candidate positions
+// chunk * 28 + group, stepping 28 * SCAN_CHUNKS
+__global__ void __launch_bounds__(256) corr_scan_kernel(const float* __restrict__ qn, const float* __restrict__ rn, int C, int Hq, int Wq,
+                                                         int Hr, int Wr, const float* __restrict__ inv,
+                                                         const ScanItem* __restrict__ items, const int* __restrict__ flags,
+                                                         unsigned long long* __restrict__ keys) {
+  const int count = min(flags[1], SCAN_CAP);
+  const int l = threadIdx.x & 63, grp = l / 9, tap = l - grp * 9;
+  if (grp >= 7) return;
+  const int g = (threadIdx.x >> 6) * 7 + grp;   // 0..27
+  const int Hrp = Hr - 2, Wrp = Wr - 2, Nr = Hrp * Wrp;
+  for (int it = blockIdx.y; it < count; it += gridDim.y) {
+    const ScanItem item = items[it];
+    const ExactScorer score = make_scorer(qn, rn, inv, C, Hq, Wq, Hr, Wr, item.q, tap, grp * 9);
+    const int jl = item.lane;
+    const int N = jl < 0 ? Nr : ((jl < WP && jl < Wrp) ? ((Wrp - jl + WP - 1) / WP) * Hrp : 0);
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int p = blockIdx.x * 28 + g; p < N; p += 28 * gridDim.x) {
+      const int n = jl < 0 ? p : (p % Hrp) * Wrp + jl + WP * (p / Hrp);
+      const float v = score(n);
+      if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+    }
+    if (tap == 0 && bidx != 0x7fffffff) atomicMax(&keys[item.q], pack_key(best, bidx));
+  }
+}
+
+__global__ void __launch_bounds__(256) corr_scan_finish_kernel(const ScanItem* __restrict__ items, const int* __restrict__ flags,
+                                                                const unsigned long long* __restrict__ keys,
+                                                                const float* __restrict__ qden, int norm_input,
+                                                                int64_t* __restrict__ max_idx, float* __restrict__ max_val) {
+  const int count = min(flags[1], SCAN_CAP);
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < count; it += gridDim.x * 256) {
+    const long long q = items[it].q;
+    float v;
+    int n;
+    unpack_key(keys[q], v, n);
     if (norm_input) v = v / qden[q];
-    max_idx[q] = (int64_t)bidx;
+    max_idx[q] = (int64_t)n;     // (several items of one query write the same pair)
     max_val[q] = v;
   }
 }
@@ -485,9 +583,11 @@ static int launch_filter_c(hipStream_t st, const _Float16* qpl, const _Float16* 
                            const float* sc, const float* band, const int2* skip, int* cnt, int* cand) {
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB) + 2 * (size_t)C * 128;
-  static unsigned long long lds_set = 0;
-  auto kern = &corr_filter_kernel<C>;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set)) return rc;
+  // operand prefetch distance in k steps ($C2M_CORR_PF = 1 / 2: A/B measurement; 2 leaves no register to spare at C = 256)
+  static const int pf = [] { const char* e = getenv("C2M_CORR_PF"); return (e && e[0] == '1') ? 1 : 2; }();
+  static unsigned long long lds_set[2] = {0, 0};
+  auto kern = pf == 1 ? &corr_filter_kernel<C, 1> : &corr_filter_kernel<C, 2>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set[pf - 1])) return rc;
   ProfileScope prof(C2M_KERNEL_CORR_FILTER, st);
   hipLaunchKernelGGL(kern, dim3(B * tiles_y * tiles_x), dim3(NTHR), lds, st, qpl, rimg, Hq, Wq, Hr, Wr, tiles_y, tiles_x, sc, band,
                      skip, cnt, cand);
@@ -506,6 +606,8 @@ int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, in
   int* cnt = reinterpret_cast<int*>(wsbase + ws.cnt);
   int* cand = reinterpret_cast<int*>(wsbase + ws.cand);
   int* flags = reinterpret_cast<int*>(wsbase + ws.flags);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(wsbase + ws.keys);
+  ScanItem* items = reinterpret_cast<ScanItem*>(wsbase + ws.items);
   const int HWq = Hq * Wq, HWr = Hr * Wr, Hqp = Hq - 2, Wqp = Wq - 2, Hrp = Hr - 2, Wrp = Wr - 2;
   const int nxt = ceil_div(Wrp, WP);
   const long long nqp = (long long)B * Hqp * Wqp, npix_r = (long long)B * HWr;
@@ -529,7 +631,10 @@ int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, in
   {
     ProfileScope prof(C2M_KERNEL_CORR_RESOLVE, st);
     hipLaunchKernelGGL(corr_resolve_kernel, dim3((unsigned)((nqp + 27) / 28)), dim3(256), 0, st, qn, rn, C, Hq, Wq, Hr, Wr, inv, qden,
-                       norm_input, cnt, cand, nqp, max_idx, max_val);
+                       norm_input, cnt, cand, nqp, keys, items, flags, max_idx, max_val);
+    hipLaunchKernelGGL(corr_scan_kernel, dim3(SCAN_CHUNKS, SCAN_STRIPES), dim3(256), 0, st, qn, rn, C, Hq, Wq, Hr, Wr, inv, items, flags,
+                       keys);
+    hipLaunchKernelGGL(corr_scan_finish_kernel, dim3(8), dim3(256), 0, st, items, flags, keys, qden, norm_input, max_idx, max_val);
   }
   return check_launch();
 }

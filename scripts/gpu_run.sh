@@ -35,6 +35,14 @@ for stage in "$@"; do
                 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_fetch.log 2>&1
                 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc_write -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_write.log 2>&1
                 cd $R ;;
+    pmc_corr)   cd /tmp
+                timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --kernel-trace -f csv -d $O/pmc_corr1 -o c -- python $R/bench.py --workload corr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_corr1.log 2>&1
+                timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -f csv -d $O/pmc_corr2 -o c -- python $R/bench.py --workload corr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_corr2.log 2>&1
+                timeout 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -f csv -d $O/pmc_corr3 -o c -- python $R/bench.py --workload corr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_corr3.log 2>&1
+                cd $R
+                (python scripts/pmc_kernel.py $O/pmc_corr1 corr; python scripts/pmc_kernel.py $O/pmc_corr2 corr; python scripts/pmc_kernel.py $O/pmc_corr3 corr) > $O/pmc_corr_summary.txt 2>&1
+                rm -rf $O/pmc_corr1 $O/pmc_corr2 $O/pmc_corr3 ;;
+    diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac
 done

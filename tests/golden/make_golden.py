@@ -313,6 +313,26 @@ def make_metrics():
     np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), **out)
 
 
+SAMPLER_CASES = [(11, 3, 4), (7, 100, 2), (64, 1, 8), (5, 2, 3)]   # (len(dataset), ratio, world)
+
+
+def make_sampler():
+    """Index lists of the reference's DistIterSampler (mmsr/data/data_sampler.py:8-69) for every rank of a few (dataset size,
+    ratio, world size) cases at epochs 0 and 5 -- the class is plain torch and imports as it is."""
+    spec = importlib.util.spec_from_file_location("data_sampler_reference", f"{REF}/mmsr/data/data_sampler.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = {}
+    for (n, ratio, world) in SAMPLER_CASES:
+        for epoch in (0, 5):
+            for rank in range(world):
+                smp = m.DistIterSampler(list(range(n)), num_replicas=world, rank=rank, ratio=ratio)
+                smp.set_epoch(epoch)
+                out[f"n{n}_r{ratio}_w{world}_e{epoch}_rank{rank}"] = np.array(list(iter(smp)), np.int64)
+    np.savez_compressed(os.path.join(HERE, "sampler_golden.npz"), **out)
+    print("sampler:", len(out), "index lists")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -390,3 +410,5 @@ if __name__ == "__main__":
         make_cfg5()
     if what in ("metrics", "all"):
         make_metrics()
+    if what in ("sampler", "all"):
+        make_sampler()
