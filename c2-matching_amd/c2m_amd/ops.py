@@ -307,36 +307,49 @@ class _WeightCache:
     forward that uses it; ``clear()`` drops everything (clear_weight_caches)."""
 
     def __init__(self):
+        import threading
         self._d = {}
         self._tables = {}    # refresh job tables: frozenset(param ids) | None -> (signature, device int64 [n, 8], nblocks, any_f16)
+        # nn.DataParallel runs the fused forwards of its replicas on one Python thread per GPU: every access to the two
+        # dicts goes through this lock (re-entrant: refresh() -> redo() -> _relayout() stays on one thread)
+        self._lock = threading.RLock()
 
     def _lookup(self, slot, key, weight):
-        hit = self._d.get(slot)
+        with self._lock:
+            hit = self._d.get(slot)
         if hit is not None and hit[0] == key and hit[2]() is weight:
             return hit[1]
         return None
 
     def _store(self, slot, key, weight, value, redo=None):
         import weakref
-        d = self._d
+        d, lock = self._d, self._lock
 
         def _drop(ref, slot=slot):
-            cur = d.get(slot)
-            if cur is not None and cur[2] is ref:
-                del d[slot]
-        self._d[slot] = (key, value, weakref.ref(weight, _drop), redo)
+            with lock:
+                cur = d.get(slot)
+                if cur is not None and cur[2] is ref:
+                    del d[slot]
+        with lock:
+            self._d[slot] = (key, value, weakref.ref(weight, _drop), redo)
 
     def clear(self):
-        self._d.clear()
-        self._tables.clear()
+        with self._lock:
+            self._d.clear()
+            self._tables.clear()
 
     _SPLIT_PIECES = {3: 3, 4: 1, 5: 3, 6: 2}     # cache kind -> pieces of the split-kernel image
 
-    def refresh(self, param_ids=None):
+    def refresh(self, param_ids=None, kinds=None):
+        with self._lock:
+            return self._refresh_locked(param_ids, kinds)
+
+    def _refresh_locked(self, param_ids=None, kinds=None):
         """Re-run the re-layout of the live entries (of the tensors whose id() is in param_ids, or all) from the tensors'
         current contents.  The split-kernel images -- nearly all of them -- go through ONE multi-tensor call
         (c2m_conv3x3_relayout_split_multi: a device job table, rebuilt only when the set of images changes); the rest
-        (fp32-MFMA kernels' layouts, padded input channels) one call per image."""
+        (fp32-MFMA kernels' layouts, padded input channels) one call per image.  kinds: restrict to these cache kinds (an
+        inference forward has no use for the autograd path's images, and vice versa)."""
         n = 0
         jobs, sig, dev = [], [], None
         for slot, (key, value, ref, redo) in list(self._d.items()):
@@ -346,6 +359,8 @@ class _WeightCache:
             if key[0] != w.data_ptr() or key[1] != w._version:
                 continue        # stale by key: the next get() rebuilds it anyway
             rows, kind = (slot[1], slot[2]) if isinstance(slot, tuple) and len(slot) == 3 else (None, None)
+            if kinds is not None and kind is not None and kind not in kinds:
+                continue
             if kind in self._SPLIT_PIECES and len(key) == 5 and key[3] is None and w.is_contiguous() and (dev is None or dev == w.device):
                 dev = w.device
                 Co, Ci = (rows[1] - rows[0] if rows is not None else w.shape[0]), w.shape[1]
@@ -360,15 +375,19 @@ class _WeightCache:
                 redo(w, value)
             n += 1
         if jobs:
-            tkey = None if param_ids is None else frozenset(param_ids)
+            tkey = (None if param_ids is None else frozenset(param_ids), None if kinds is None else frozenset(kinds))
             sig = tuple(sig)
             tab = self._tables.get(tkey)
             if tab is None or tab[0] != sig:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.C2MError("weight-cache refresh: the set of cached weight images changed during a hipGraph capture (its "
+                                        "job table would need a host-to-device copy); run one eager forward before capturing")
                 rowsl, first = [], 0
                 for (wptr, iptr, ci, co, flags, elems) in jobs:
                     rowsl.append([wptr, iptr, ci, co, flags, elems, first, 0])
                     first += (elems + 255) // 256
-                tab = (sig, torch.tensor(rowsl, dtype=torch.int64).to(dev), first, int(any((j[4] & 0xff) == 2 for j in jobs)))
+                host = torch.tensor(rowsl, dtype=torch.int64).pin_memory()
+                tab = (sig, host.to(dev, non_blocking=True), first, int(any((j[4] & 0xff) == 2 for j in jobs)), host)
                 if len(self._tables) >= 64:      # (tables of parameter sets that no longer exist: a handful of KiB each)
                     self._tables.clear()
                 self._tables[tkey] = tab
@@ -464,6 +483,81 @@ _FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16", "sp
 _EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0, 6.0, 3.0)
 
 
+# ---- f16 x 2 is the DEFAULT arithmetic of fp32 inference, and its domain is |activation| < 65520: outside it the kernel
+# writes NaN where nn.Conv2d (arch_util.py:80-136) returns a number.  Every f16 x 2 launch therefore reports out-of-range
+# inputs into a per-device flag (c2m_conv3x3_desc.range_flag), and the fused module forwards run under `f16_range_guard`: the
+# flag is zeroed before, read once after (one 4-byte read-back per module forward), and if it is set the forward is repeated
+# on the bf16 x 3 flavour (full fp32 exponent range) -- the module is then pinned to that flavour.
+import threading as _threading
+
+_tls = _threading.local()
+_range_flags = {}
+_range_lock = _threading.Lock()
+
+
+def _range_flag(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _range_flags.get(key)
+    if t is None:
+        with _range_lock:
+            t = _range_flags.get(key)
+            if t is None:
+                t = _range_flags[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def _split16_now():
+    """f16 x 2 (True) or bf16 x 3 (False) for an fp32 split-kernel call of this thread right now."""
+    ov = getattr(_tls, "flavour", None)
+    return _SPLIT16 if ov is None else ov
+
+
+class conv_flavour:
+    """`with ops.conv_flavour("bf16x3"): ...` / ("f16x2"): the fp32 split-kernel flavour of this thread's conv3x3 calls inside
+    the block (overrides $C2M_CONV_SPLIT16)."""
+
+    def __init__(self, name):
+        if name not in ("f16x2", "bf16x3"):
+            raise _lib.C2MError("conv_flavour: 'f16x2' or 'bf16x3'")
+        self.val = name == "f16x2"
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "flavour", None)
+        _tls.flavour = self.val
+        return self
+
+    def __exit__(self, *exc):
+        _tls.flavour = self.prev
+        return False
+
+
+def f16_range_guard(owner, fn, device):
+    """Run `fn()` (a fused forward made of conv3x3 calls) so that it never returns f16 x 2 overflow garbage: see above.
+    `owner` (an nn.Module or any object) remembers the pinned flavour in `owner._c2m_conv_bf16x3`."""
+    if getattr(owner, "_c2m_conv_bf16x3", False) or not _split16_now() or bf16_autocast():
+        if getattr(owner, "_c2m_conv_bf16x3", False):
+            with conv_flavour("bf16x3"):
+                return fn()
+        return fn()
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.C2MError("f16_range_guard: the range check reads a flag back and cannot run inside a hipGraph capture; use "
+                            "ops.conv_flavour('bf16x3') (full fp32 range, no check) for captured inference")
+    flag = _range_flag(device)
+    flag.zero_()
+    out = fn()
+    if int(flag.item()) == 0:
+        return out
+    import warnings
+    warnings.warn(f"{type(owner).__name__}: an activation left the f16 x 2 convolution flavour's domain (|x| >= 65520); the forward "
+                  "was recomputed on the bf16 x 3 flavour (full fp32 range), which this module now keeps", RuntimeWarning)
+    try:
+        owner._c2m_conv_bf16x3 = True
+    except Exception:  # noqa: BLE001 -- an owner without attributes: just recompute
+        pass
+    with conv_flavour("bf16x3"):
+        return fn()
+
+
 def _wino_ok(srcs, weight, out_mode, W):
     """Winograd F(2,3)-along-x kernel: channels-last output, 64-wide cout tiles, whole 32-pixel tiles along x."""
     return (_WINO and out_mode in ("nhwc", "nhwc_pool2") and weight.shape[0] % 64 == 0 and W % 32 == 0 and
@@ -515,7 +609,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         reduced = bf16_autocast()
         if (out2_grouped8 is None and (_split_ok(srcs, weight, fast) or (reduced and _split_ok(srcs, weight, True))) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
                 and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
-            wino = 4 if reduced else 6 if _SPLIT16 else 3
+            wino = 4 if reduced else 6 if _split16_now() else 3
         else:
             wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
@@ -569,6 +663,8 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     else:
         raise _lib.C2MError(f"unknown out_mode {out_mode}")
     d.out = out.data_ptr()
+    if wino == 6:
+        d.range_flag = _range_flag(dev).data_ptr()
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     if _ConvFlops.enabled:
@@ -772,7 +868,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
     slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
     use_split = algo in ("split", "bf16", "split16") or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
     split_id = (4 if (algo == "bf16" or (algo is None and bf16_autocast())) else
-                6 if (algo == "split16" or (algo is None and _SPLIT16)) else 3)
+                6 if (algo == "split16" or (algo is None and _split16_now())) else 3)
     fam = []
     for (c0, c1) in slices:
         # split-bf16 kernel (any shape); else 64-channel-tileable slices on whole 32-pixel tiles take the Winograd F(2,3)
@@ -795,6 +891,8 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
             d.flow, d.fh, d.fw = flow.data_ptr(), flow.shape[1], flow.shape[2]
         if abs_sum is not None:
             d.abs_sum = abs_sum.data_ptr()
+        if wino == 6:
+            d.range_flag = _range_flag(dev).data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     if _ConvFlops.enabled:
@@ -861,9 +959,11 @@ class _DcnWeightCache(_WeightCache):
 _dcn_wcache = _DcnWeightCache()
 
 
-def refresh_weight_caches(module_or_params=None):
+def refresh_weight_caches(module_or_params=None, all_kinds=False):
     """Rebuild the cached weight images (conv3x3 re-layouts, DCNv2 re-layouts) of the given module's / iterable's
-    parameters -- or of every live entry -- from the tensors' CURRENT contents.  The fused inference entry points call
+    parameters -- or of every live entry -- from the tensors' CURRENT contents; unless all_kinds, only the images the
+    CURRENT path multiplies with (no-grad forward: the f16 x 2 / bf16 / bf16 x 3 forward images of the active flavour and the
+    fp32-MFMA layouts, not the autograd path's data-gradient images).  The fused inference entry points call
     this once per forward: in-place writes through ``param.data`` do not bump the version counter the caches are keyed
     on, so without it such an update would keep computing with the old weights.  Returns the number of
     images rebuilt.  No host synchronisation."""
@@ -873,7 +973,10 @@ def refresh_weight_caches(module_or_params=None):
     if module_or_params is not None:
         params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
         ids = {id(p) for p in params}
-    return _wcache.refresh(ids) + _dcn_wcache.refresh(ids)
+    kinds = None
+    if not all_kinds and not torch.is_grad_enabled():
+        kinds = {0, 1, 2, 4 if bf16_autocast() else 6 if _split16_now() else 3}
+    return _wcache.refresh(ids, kinds) + _dcn_wcache.refresh(ids)
 
 
 def clear_weight_caches():

@@ -1561,6 +1561,7 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.cout_total = cout_total;
   p.out2 = d->out2; p.out2_row_pitch = d->out2_row_pitch; p.out2_plane_pitch = d->out2_plane_pitch;
   p.out2_img_pitch = d->out2_img_pitch;
+  p.range_flag = d->range_flag;
   if (d->out2 && (wino || d->out_mode != 0 || !out_vec4 || d->Cout % 8 != 0 || ((uintptr_t)d->out2 & 15) ||
                   d->out2_row_pitch % 4 != 0 || d->out2_plane_pitch % 4 != 0 || d->out2_img_pitch % 4 != 0))
     return C2M_ERR_UNSUPPORTED;

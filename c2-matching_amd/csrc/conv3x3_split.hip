@@ -390,11 +390,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // (l >> 2), quad q = l & 3) -> plane slab (q >> 1), 8 bytes at pixel*16 + (q & 1)*8.
   const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;   // + r * 1024 + plane * 2*HALFB
   u32x2 cq[3];
+  float amax = 0.0f;   // f16 x 2: largest |activation| this lane has split (domain check, Params::range_flag)
   auto conv_split = [&](const f32x4 v) __attribute__((always_inline)) {
     if constexpr (FL == 3) {
       split3(v, cq[0], cq[1], cq[2]);
     } else if constexpr (FL == 2) {
       split2_f16(v, cq[0], cq[1]);
+      amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+      amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
     } else {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 h;
@@ -759,6 +762,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+  }
+  if constexpr (FL == 2) {
+    if (p.range_flag != nullptr && !(amax < 65520.0f)) *p.range_flag = 1;   // (rare, idempotent store; inf counts)
   }
 }
 

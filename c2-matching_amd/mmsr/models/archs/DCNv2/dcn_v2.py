@@ -16,6 +16,8 @@ import logging
 import math
 
 import _ext as _backend
+import threading
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -185,6 +187,29 @@ class DCNv2(nn.Module):
         return self._conv(input, offset, mask)
 
 
+_kernel_choice = threading.local()
+
+
+class use_conv_kernels:
+    """`with use_conv_kernels(True / False): ...` -- whether the offset/mask heads of the DCN modules called inside the block
+    (on this thread) run the hand-written autograd kernels (c2m_amd.ops.conv3x3_autograd) or the stock nn.Conv2d."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = getattr(_kernel_choice, 'on', None)
+        _kernel_choice.on = self.on
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            del _kernel_choice.on
+        else:
+            _kernel_choice.on = self.prev
+        return False
+
+
 class _SelfOffsetDCN(DCNv2):
     """Shared machinery of DCN / DCN_sep / DCN_sep_pre_multi_offset: a `conv_offset_mask` head (zero-initialised,
     dg*3*kh*kw channels, same kernel/stride/padding as the main conv -- dcn_v2.py:112-124) feeding the fused
@@ -199,8 +224,11 @@ class _SelfOffsetDCN(DCNv2):
         self.init_offset()
         self._watch = _OffsetMeanWatch()
 
-    #: False: the offset/mask head always runs as the stock nn.Conv2d (RestorationNet.allow_fused = False sets it)
-    allow_conv_kernels = True
+    #: Default policy for the offset/mask head under autograd: False = the stock nn.Conv2d (double backward works, MIOpen is
+    #: the faster choice on small maps); True = the hand-written forward / backward kernels.  A parent that has measured
+    #: the choice for its sizes (RestorationNet: $C2M_TRAIN_KERNELS / TRAIN_KERNELS_MIN_PIXELS) overrides it for the calls it
+    #: makes with `use_conv_kernels(...)` -- a thread-local context, not a mutation of this (shared) module.
+    allow_conv_kernels = False
 
     def init_offset(self):
         self.conv_offset_mask.weight.data.zero_()
@@ -208,7 +236,7 @@ class _SelfOffsetDCN(DCNv2):
 
     def _offset_and_mask(self, feat, pre_offset=None, watch=False):
         head = self.conv_offset_mask
-        if (self.allow_conv_kernels and torch.is_grad_enabled() and feat.is_cuda and feat.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
+        if (getattr(_kernel_choice, 'on', self.allow_conv_kernels) and torch.is_grad_enabled() and feat.is_cuda and feat.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and
                 head.kernel_size == (3, 3) and head.stride == (1, 1) and head.padding == (1, 1) and
                 not head._forward_hooks and not head._forward_pre_hooks and _ops.conv3x3_autograd_ok([feat], head.weight)):
             raw = _ops.conv3x3_autograd([feat], head.weight, head.bias)   # hand-written forward / backward kernels (training)

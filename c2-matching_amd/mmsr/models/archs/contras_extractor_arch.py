@@ -20,7 +20,10 @@ class ContrasExtractorLayer(nn.Module):
                 (not torch.is_autocast_enabled('cuda') or _ops.bf16_autocast())):
             # inference: the five convolutions (+ ReLU) on the fused channels-last kernel; conv3_1 (no ReLU,
             # contras_extractor_arch.py:21-23) is written planar for the correlation kernels
-            out = _ops.vgg_stack_forward(self.model._modules, batch, mean=self.mean, std=self.std, last_nchw=True)
+            # (f16_range_guard: the default f16 x 2 convolution flavour covers |activation| < 65520; an input that leaves
+            # it -- un-normalised 0..255 images, say -- is detected on the device and the stack recomputed on bf16 x 3)
+            out = _ops.f16_range_guard(self, lambda: _ops.vgg_stack_forward(self.model._modules, batch, mean=self.mean, std=self.std,
+                                                                              last_nchw=True), batch.device)
             return out['conv3_1']
         return self.model((batch - self.mean) / self.std)
 

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 import mmsr.models.archs.arch_util as arch_util
 from c2m_amd import ops as _ops
 from mmsr.models.archs.DCNv2.dcn_v2 import DCN_sep_pre_multi_offset as DynAgg
-from mmsr.models.archs.DCNv2.dcn_v2 import FusedPreOffset
+from mmsr.models.archs.DCNv2.dcn_v2 import FusedPreOffset, use_conv_kernels
 
 
 class ContentExtractor(nn.Module):
@@ -262,14 +262,16 @@ class RestorationNet(nn.Module):
         """x: LR image [B,3,h,w]; pre_offset / img_ref_feat: dicts keyed relu3_1 / relu2_1 / relu1_1."""
         base = F.interpolate(x, None, 4, 'bilinear', False)
         if self._use_fused(x, pre_offset, img_ref_feat):
-            _ops.refresh_weight_caches(self)   # cached weight images follow writes through .data (no version bump)
-            content_feat = self.content_extractor.forward_fused(x)
-            return self.dyn_agg_restore.forward_fused(content_feat, pre_offset.flow, img_ref_feat) + base
+            def fused():
+                _ops.refresh_weight_caches(self)   # cached weight images follow writes through .data (no version bump)
+                content_feat = self.content_extractor.forward_fused(x)
+                return self.dyn_agg_restore.forward_fused(content_feat, pre_offset.flow, img_ref_feat)
+            # (the f16 x 2 convolution flavour's domain is |activation| < 65520: checked on the device, bf16 x 3 re-run if left)
+            return _ops.f16_range_guard(self, fused, x.device) + base
         train_kernels = self._use_train_kernels(x, img_ref_feat)
-        for name, _, _ in DynamicAggregationRestoration._STAGES:   # the DynAgg heads follow this net's choice
-            getattr(self.dyn_agg_restore, f'{name}_dyn_agg').allow_conv_kernels = train_kernels
-        if train_kernels:
-            content_feat = self.content_extractor.forward_train(x)
-            return self.dyn_agg_restore.forward_train(content_feat, pre_offset, img_ref_feat) + base
-        content_feat = self.content_extractor(x)
-        return self.dyn_agg_restore(content_feat, pre_offset, img_ref_feat) + base
+        with use_conv_kernels(train_kernels):   # the DynAgg heads follow this net's choice (thread-local, no module state)
+            if train_kernels:
+                content_feat = self.content_extractor.forward_train(x)
+                return self.dyn_agg_restore.forward_train(content_feat, pre_offset, img_ref_feat) + base
+            content_feat = self.content_extractor(x)
+            return self.dyn_agg_restore(content_feat, pre_offset, img_ref_feat) + base

@@ -135,10 +135,10 @@ class VGGFeatureExtractor(nn.Module):
             # inference on the gfx950 channels-last kernels: conv + ReLU in one launch, tapped activations written straight
             # into the zero-bordered channels-last buffers the DCNv2 warps gather from (no clone, no layout copy)
             from c2m_amd import ops as _ops
-            return _ops.vgg_stack_forward(self.vgg_net._modules, x, taps=self.layer_name_list,
-                                          mean=self.mean if self.use_input_norm else None,
-                                          std=self.std if self.use_input_norm else None,
-                                          grouped8_taps=getattr(self, 'grouped8_taps', ()), fast=getattr(self, 'fast_conv', False))
+            return _ops.f16_range_guard(self, lambda: _ops.vgg_stack_forward(
+                self.vgg_net._modules, x, taps=self.layer_name_list, mean=self.mean if self.use_input_norm else None,
+                std=self.std if self.use_input_norm else None, grouped8_taps=getattr(self, 'grouped8_taps', ()),
+                fast=getattr(self, 'fast_conv', False)), x.device)
         if self.use_input_norm:
             x = (x - self.mean) / self.std
         taps = {}

@@ -44,8 +44,10 @@ class RefRestorationModel(BaseModel):
             self.load_network(self.net_extractor, path['pretrain_model_feature_extractor'], path.get('strict_load', True))
         if path.get('pretrain_model_g'):
             self.load_network(self.net_g, path['pretrain_model_g'], path.get('strict_load', True))
+        # (one process, ONE device: nn.DataParallel's scatter / replicate / worker threads cannot be captured)
         self._graph_on = bool(self.is_train and (self.opt.get('train') or {}).get('hip_graph') and not self.opt.get('dist')
-                              and self.device.type == 'cuda')
+                              and self.device.type == 'cuda' and not isinstance(self.net_g, torch.nn.DataParallel))
+        self._eval_feed = False   # True while a validation loop feeds data: its batches bypass the graph's static buffers
         self._graph, self._graph_calls, self._static = None, 0, None
         if self.is_train:
             self.net_g.train()
@@ -77,7 +79,7 @@ class RefRestorationModel(BaseModel):
     _FEED = (('img_in_lq', 'img_in_lq'), ('img_ref', 'img_ref'), ('gt', 'img_in'), ('match_img_in', 'img_in_up'))
 
     def feed_data(self, data):
-        if self._graph_on:
+        if self._graph_on and not self._eval_feed:
             # static input buffers: the captured step reads these addresses; a new batch is copied INTO them
             shapes = {a: tuple(data[k].shape) for a, k in self._FEED}
             if self._static is None or {a: tuple(t.shape) for a, t in self._static.items()} != shapes:
@@ -147,7 +149,11 @@ class RefRestorationModel(BaseModel):
         for idx, val_data in enumerate(dataloader):
             if idx % world != rank:
                 continue
-            self.feed_data(val_data)
+            self._eval_feed = True    # (differently shaped validation pairs must not reset the captured training step)
+            try:
+                self.feed_data(val_data)
+            finally:
+                self._eval_feed = False
             sr = self.test()
             gt = self.gt
             if val_data.get('padding', False) is not False and bool(torch.as_tensor(val_data['padding']).any()):

@@ -275,6 +275,12 @@ typedef struct c2m_conv3x3_desc {
                               what c2m_dcn_v2_forward_nhwc_f32(input_grouped = 1) gathers from.  Cout % 8 == 0 */
   int out2_row_pitch;
   long long out2_plane_pitch, out2_img_pitch;
+  int* range_flag;         /* C2M_CONV_SPLIT_F16X2 only, or NULL: device int the kernel sets to 1 when an input activation lies
+                              outside the flavour's domain (|x| >= 65520: the output then holds NaN).  Never cleared by the
+                              kernel: the caller zeroes it, runs any number of convolutions and reads it once -- if set, the
+                              results are to be recomputed with C2M_CONV_SPLIT_BF16X3 (what c2m_amd.ops.f16_range_guard and
+                              the fused module forwards do, so that a drop-in never returns NaN where nn.Conv2d returns a
+                              number: arch_util.py:80-136) */
 } c2m_conv3x3_desc;
 
 size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */
