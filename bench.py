@@ -133,23 +133,19 @@ def _tf(flops, ms):
     return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
 
+def _rnd(x, n=4):
+    return None if x is None else round(float(x), n)
+
+
 def corr_roofline(B, C, h, kms, n, pmc, swept=None):
+    """Exact fp32-MFMA sweep (csrc/corr_argmax.hip; the pre-filter's fall-back and `c2m_feature_match_set_filter(0)`)."""
     exec_flops = corr_executed_flops(B, C, h, swept[0] if swept else None)
-    useful = B * 2.0 * (h * h) ** 2 * C                      # pixel-level products D[p][r]: the restructured minimum
     algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9             # SURVEY.md 8d: 2*Nq*Nr*C*9 per pair
-    return {"bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"corr_argmax_mfma_kernel<{C}>", "achieved": _tf(exec_flops, kms),
-            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(exec_flops, kms) / FP32_MATRIX_PEAK_TFLOPS,
-            "frac_definition": "executed fp32 MFMA flops / peak (hardware utilisation, <= 1)",
-            "traffic": pmc.get("corr_hbm_bytes_per_launch"), "traffic_source": pmc.get("source"),
-            "kernel_ms": kms, "launches_timed": n,
-            "frac_useful_flops": _tf(useful, kms) / FP32_MATRIX_PEAK_TFLOPS,
-            "executed_flops_per_launch": exec_flops, "useful_flops_per_launch": useful,
-            "algorithmic_flops_per_launch": algo, "algorithmic_equiv_tflops": _tf(algo, kms),
-            "algorithmic_note": "SURVEY 8d's figure is the reference's conv2d formulation, 8.6x the work this kernel needs (the "
-                                "9-tap patch sum is taken over pixel-level dot products): its rate exceeds the peak",
-            "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None,
-            "duplicate_row_elimination": "ref rows that repeat the three rows above them bit for bit (the zero-padding band "
-                                         "of a 500x500 Ref) are not swept: exact, data-dependent (no such rows -> full sweep)"}
+    return {"k": "corr_exact_sweep", "bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"corr_argmax_mfma_kernel<{C}>", "achieved": _rnd(_tf(exec_flops, kms), 2),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _rnd(_tf(exec_flops, kms) / FP32_MATRIX_PEAK_TFLOPS),
+            "traffic": pmc.get("corr_hbm_bytes_per_launch"), "kernel_ms": _rnd(kms, 3), "launches_timed": n,
+            "executed_flops_per_launch": exec_flops, "algorithmic_flops_per_launch": algo,
+            "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None}
 
 
 def corr_filter_roofline(B, C, h, kern, pmc, swept=None):
@@ -161,19 +157,19 @@ def corr_filter_roofline(B, C, h, kern, pmc, swept=None):
     rows = swept[0] if swept else B * ((h - 2 + 27) // 28) * h
     execd = tiles * (rows + B) * 8 * (3 * C // 16) * (2 * 32 * 32 * 16)
     algo = B * 2.0 * ((h - 2) ** 2) ** 2 * C * 9
-    return {"bound": "mfma", "pipe": "f16 MFMA", "kernel": f"corr_filter_kernel<{C}> (+ corr_resolve_kernel: exact fp32 re-score)",
-            "achieved": _tf(execd, fms), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(execd, fms) / BF16_MATRIX_PEAK_TFLOPS,
-            "traffic": pmc.get("corr_filter_hbm_bytes_per_launch"), "kernel_ms": fms, "launches_timed": len(fk),
-            "resolve_ms": sum(rk) / max(len(rk), 1), "executed_flops_per_launch": execd, "algorithmic_flops_per_launch": algo,
-            "algorithmic_equiv_tflops": _tf(algo, fms + sum(rk) / max(len(rk), 1)),
+    return {"k": "corr_filter", "bound": "mfma", "pipe": "f16 MFMA", "kernel": f"corr_filter_kernel<{C}> (+ corr_resolve: exact fp32 re-score)",
+            "achieved": _rnd(_tf(execd, fms), 1), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": _rnd(_tf(execd, fms) / BF16_MATRIX_PEAK_TFLOPS), "traffic": pmc.get("corr_filter_hbm_bytes_per_launch"),
+            "kernel_ms": _rnd(fms, 3), "launches_timed": len(fk), "resolve_ms": _rnd(sum(rk) / max(len(rk), 1), 3),
+            "executed_flops_per_launch": execd, "algorithmic_flops_per_launch": algo,
             "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None}
 
 
 def dcn_roofline(name, B, C, Co, H, kms, n, traffic=None, src=None):
     flops = B * 2.0 * Co * 9 * C * H * H                     # 2*Co*(9C)*H*W per sample (executed = algorithmic)
-    return {"bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": _tf(flops, kms),
-            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _tf(flops, kms) / FP32_MATRIX_PEAK_TFLOPS,
-            "traffic": traffic, "traffic_source": src, "kernel_ms": kms, "launches_timed": n, "algorithmic_flops_per_launch": flops}
+    return {"k": f"dcn_{name}", "bound": "mfma", "pipe": "fp32 MFMA", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]", "achieved": _rnd(_tf(flops, kms), 2),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _rnd(_tf(flops, kms) / FP32_MATRIX_PEAK_TFLOPS),
+            "traffic": traffic, "kernel_ms": _rnd(kms, 3), "launches_timed": n, "algorithmic_flops_per_launch": flops}
 
 
 def _is_split_family(k):
@@ -182,7 +178,7 @@ def _is_split_family(k):
 
 def conv_rooflines(kern, fam, steps, pmc):
     """The 3x3 convolutions of one step, split by the matrix pipe they run on.  fam = ops.conv_flops_by_family() of the
-    timed steps: {family: [launches, algorithmic flops, executed matrix flops]}."""
+    timed steps: {family: [launches, algorithmic flops, executed matrix flops]}.  (What the kernels are: profiles/bench_notes.md.)"""
     out = []
     for kid, pipe, peak in (("conv3x3_split", "f16 / bf16 MFMA", BF16_MATRIX_PEAK_TFLOPS), ("conv3x3_mfma", "fp32 MFMA", FP32_MATRIX_PEAK_TFLOPS)):
         ms = kern.get(kid, [])
@@ -192,28 +188,13 @@ def conv_rooflines(kern, fam, steps, pmc):
         algo = sum(v[1] for v in mine.values()) / steps
         execd = sum(v[2] for v in mine.values()) / steps
         kms = sum(ms) / steps
-        e = {"bound": "mfma", "pipe": pipe,
-             "kernel": ("conv3x3_split_kernel (csrc/conv3x3_split.hip: fp32-accurate 3x3 convolution on the 16-bit matrix pipe.  fp32 "
-                        "inference: f16 x 2 flavour -- activations as two round-to-nearest f16 pieces, weights scaled per tensor and "
-                        "split the same way, THREE MFMAs per product sum; autograd / $C2M_CONV_SPLIT16=0: bf16 x 3 flavour, six MFMAs; "
-                        "bf16 autocast: one piece, one MFMA.  Decoder, DCN heads, VGG19 taps, extractor towers)"
-                        if kid == "conv3x3_split" else
-                        "conv3x3_kernel / conv3x3_wino*_kernel / conv3x3_c3_kernel (csrc/conv3x3.hip, fp32 MFMA: first layers of "
-                        "the image towers and whatever $C2M_CONV_SPLIT keeps off the split kernel)"),
-             "achieved": _tf(execd, kms), "peak": peak, "unit": "TFLOP/s", "frac": _tf(execd, kms) / peak,
-             "frac_definition": "executed matrix flops / dense peak of that pipe (<= 1)",
-             "kernel_ms": kms, "launches_timed": len(ms), "per": "step (sum over the step's launches)",
-             "algorithmic_flops_per_launch": algo, "executed_flops_per_launch": execd,
-             "algorithmic_equiv_tflops": _tf(algo, kms),
-             "algorithmic_equiv_frac_of_fp32_mfma_peak": _tf(algo, kms) / FP32_MATRIX_PEAK_TFLOPS,
-             "families": {k: {"launches_per_step": v[0] / steps, "algorithmic_tflop_per_step": v[1] / steps / 1e12} for k, v in mine.items()},
-             "traffic": pmc.get(f"{kid}_hbm_bytes_per_step"), "traffic_source": pmc.get("source")}
+        e = {"k": kid, "bound": "mfma", "pipe": pipe, "kernel": f"{kid}_kernel family (all launches of one step)",
+             "achieved": _rnd(_tf(execd, kms), 1), "peak": peak, "unit": "TFLOP/s", "frac": _rnd(_tf(execd, kms) / peak),
+             "kernel_ms": _rnd(kms, 2), "launches_timed": len(ms), "algorithmic_flops_per_launch": algo,
+             "executed_flops_per_launch": execd, "algorithmic_equiv_tflops": _rnd(_tf(algo, kms), 1),
+             "traffic": pmc.get(f"{kid}_hbm_bytes_per_step")}
         if kid == "conv3x3_split":
-            e["frac_of_sustained_bf16_rate"] = _tf(execd, kms) / BF16_SUSTAINED_TFLOPS
-            e["sustained_note"] = ("back-to-back v_mfma_f32_32x32x16_bf16 on every SIMD with non-zero operands sustains "
-                                   f"{BF16_SUSTAINED_TFLOPS:.0f} TF on this chip (power: ~1.7 GHz), scripts/ubench/mfma_bf16_rate.hip.  "
-                                   "The kernel itself is POWER-bound on random data: the 64->64 @640^2 layer takes 1.60 ms on N(0,1) "
-                                   "tensors and 1.13 ms on all-zero ones (same instruction stream), profiles/r03_power_experiment.txt")
+            e["frac_of_sustained_rate"] = _rnd(_tf(execd, kms) / BF16_SUSTAINED_TFLOPS)
         out.append(e)
     return out
 
@@ -275,23 +256,18 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, sr_gpu, idx_gpu, one_thread=
         stage.append(tm)
         d = (sr_gpu[b].cpu() - sr_cpu[0]).abs()
         mg = cpu_chain.mismatch_margins(feats["dense_features1"][0], feats["dense_features2"][0], idx_gpu[b], idx_cpu[0])
-        parity.append({"pair": b, "index_map_equal_fraction": float((idx_gpu[b] == idx_cpu[0]).mean()),
-                       "index_map_mismatches": len(mg), "of_queries": int(idx_gpu[b].size),
-                       "max_abs_fp64_score_margin_of_mismatches": max((abs(m[3]) for m in mg), default=0.0),
-                       "sr_max_abs_diff_unconditional": float(d.max()), "sr_pixels_over_1e-3": int((d > 1e-3).sum()),
+        parity.append({"pair": b, "index_map_flips": len(mg), "of_queries": int(idx_gpu[b].size),
+                       "max_fp64_margin_of_flips": float(f"{max((abs(m[3]) for m in mg), default=0.0):.3g}"),
+                       "sr_max_abs_diff": float(f"{float(d.max()):.3g}"), "sr_pixels_over_1e-3": int((d > 1e-3).sum()),
                        "sr_pixels": int(d.numel())})
     med = sorted(times)[len(times) // 2]
-    out = {"value": 1.0 / med, "unit": "pairs/s", "cores": threads, "kind": "port",
-           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
-           "sample": f"{len(pairs)} of the {B} pairs of one step (pairs {pairs}), one at a time after a warm-up run, median of the "
-                     f"{len(times)} timings ({', '.join(f'{t:.1f}' for t in times)} s): whole forward (extractor, correlation as "
-                     "conv2d filters + running max, pre-offsets, VGG taps, RestorationNet with oracle DCNv2) on PyTorch-CPU + C oracle",
-           "stage_s_median_run": stage[times.index(med)],
-           "parity_gpu_vs_cpu": parity,
-           "parity_note": "index-map mismatches are fp32 near-ties of the extractor features (two convolution implementations, "
-                          "same weights; the float64 score margin of the two picks is given): the correlation kernel itself is "
-                          "bit-exact on identical features.  sr_*_unconditional: CPU chain with its OWN index map",
-           "sr_max_abs_diff_given_gpu_index_map_pair0": float((sr_gpu[0].cpu() - sr_cond[0]).abs().max())}
+    out = {"value": _rnd(1.0 / med, 4), "unit": "pairs/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "physical_cores": phys,
+           "sample": f"pairs {pairs} of the step's {B}, whole forward each (PyTorch-CPU + C oracle), after a warm-up run; median of "
+                     f"{', '.join(f'{t:.1f}' for t in times)} s",
+           "stage_s": {k: _rnd(v, 2) for k, v in stage[times.index(med)].items()},
+           "parity_gpu_vs_cpu": parity,   # index maps at the IMAGE boundary (two conv implementations): profiles/bench_notes.md
+           "sr_max_abs_diff_given_gpu_index_map_pair0": float(f"{float((sr_gpu[0].cpu() - sr_cond[0]).abs().max()):.3g}")}
     if one_thread:
         out["one_thread"] = cpu_one_thread(ext, mp, net, lq, up, ref)
     return out
@@ -335,9 +311,9 @@ def cpu_one_thread(ext, mp, net, lq, up, ref):
         g_c(l1[:, :, :q, :q].contiguous(), pre, rf)
         t_rest = (time.perf_counter() - t0) * 16.0
     total = t_ext + t_corr + t_rest
-    return {"value": 1.0 / total, "unit": "pairs/s", "cores": 1,
-            "sample": f"one pair, one thread: extractor + VGG taps measured in full ({t_ext:.1f} s), correlation on 4 of {h - 2} query "
-                      f"rows x {(h - 2) / 4:.1f} ({t_corr:.1f} s), RestorationNet on 1/16 of the pixels x 16 ({t_rest:.1f} s)"}
+    return {"value": _rnd(1.0 / total, 5), "cores": 1,
+            "sample": f"extractor + VGG taps in full {t_ext:.1f} s, correlation 4 of {h - 2} query rows x {(h - 2) / 4:.1f} = {t_corr:.1f} s, "
+                      f"RestorationNet 1/16 of the pixels x 16 = {t_rest:.1f} s"}
 
 
 def cpu_baseline_corr(h, C, budget_s=12.0):
@@ -601,65 +577,67 @@ def main():
                                        dtraf[k] if len(dtraf) == 3 else None, pmc.get("source")))
             tot = sum(dk) / (len(dk) // 3)
             flops = sum(B * 2.0 * ch * 9 * ch * hh * hh for _, ch, hh in layers)
-            rl.append({"bound": "mfma", "pipe": "fp32 MFMA", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
-                       "achieved": _tf(flops, tot), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": _tf(flops, tot) / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel_ms": tot,
-                       "launches_timed": len(dk), "algorithmic_flops_per_launch": flops,
-                       "north_star_target": ">= 0.50 MFMA utilisation on DCNv2 forward at batch 16"})
+            rl.append({"k": "dcn_all_three", "bound": "mfma", "pipe": "fp32 MFMA", "kernel": "dcn_v2_forward[all three DynAgg layers of one step]",
+                       "achieved": _rnd(_tf(flops, tot), 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": _rnd(_tf(flops, tot) / FP32_MATRIX_PEAK_TFLOPS), "traffic": None, "kernel_ms": _rnd(tot, 3),
+                       "launches_timed": len(dk), "algorithmic_flops_per_launch": flops})
         rl += conv_rooflines(kern, fam, args.steps, pmc)
         dominant = max((r for r in rl if "all three" not in r["kernel"]), key=lambda r: r["kernel_ms"]) if rl else None
-        cfg = (f"configs[4]: CUFED5-shape inference, LR {h}x{h} / Ref 500x500 zero-padded to {4*h}x{4*h}, bf16 autocast (convolutions: "
-               f"one bf16 piece per operand, fp32 accumulation; matching and DCNv2 in fp32), {B} pairs per GPU per step" if bf16 else
-               f"configs[2]: batch-{B} full restoration forward (extractor + correlation/index map + pre-offsets + VGG taps + "
-               f"RestorationNet with 3 DCNv2 warps + decoder), LR {h}x{h}, Ref 500x500 zero-padded to {4*h}x{4*h}, SR {4*h}x{4*h}, "
-               f"fp32, {B} pairs per GPU per step")
-        line = dict(base, metric=METRIC, value=B * world * args.steps / dt, ms_per_step=dt / args.steps * 1e3,
+        cfg = (f"configs[4]: CUFED5-shape inference, LR {h}x{h} / Ref 500x500 zero-padded to {4*h}x{4*h}, bf16 autocast, {B} pairs per GPU per step"
+               if bf16 else
+               f"configs[2]: batch-{B} full restoration forward (extractor + correlation/index map + VGG taps + RestorationNet with 3 DCNv2 "
+               f"warps + decoder), LR {h}x{h}, Ref 500x500 zero-padded to {4*h}x{4*h}, SR {4*h}x{4*h}, fp32")
+        # compact per-kernel table: [ms per step, frac of the pipe's dense peak, pipe]
+        table = {r["k"]: [r["kernel_ms"], r["frac"], r["pipe"]] + ([r["resolve_ms"]] if "resolve_ms" in r else []) for r in rl}
+        line = dict(base, metric=METRIC, value=_rnd(B * world * args.steps / dt, 3), ms_per_step=_rnd(dt / args.steps * 1e3, 3),
                     dtype="bf16" if bf16 else "f32",
                     config={"workload": cfg, "parallelism": f"dp{world} (batch-sharded, no collective)"},
-                    stage_ms=stage, roofline=dominant, roofline_kernels=rl, configs1_corr_only=sub)
+                    stage_ms={k: _rnd(v, 2) for k, v in stage.items()}, kernel_table=table, roofline=dominant,
+                    c2m_kernel_ms_per_step={k: _rnd(sum(v) / args.steps, 3) for k, v in kern.items()},
+                    configs1_corr_only=sub, notes="profiles/bench_notes.md")
         if not bf16:
-            line["arithmetic"] = (
-                "fp32 tensors end to end, fp32 accumulation everywhere.  Correlation / arg-max and DCNv2: fp32 MFMA.  3x3 convolutions: "
-                "every fp32 operand enters the f16 matrix pipe as two round-to-nearest f16 pieces (x = x0 + 2^-11 x1'; weights scaled "
-                "per tensor by a power of two), three products per product sum -- measured error against float64 <= 1.5x that of the "
-                "exact-fp32-MFMA kernel at the tolerance of the other fp32 kernels (tests/test_conv_gpu.py: 1e-5 * scale); "
-                "$C2M_CONV_SPLIT16=0 runs the bf16 x 3 flavour (six products, full fp32 exponent range), $C2M_CONV_SPLIT=0 the "
-                "fp32-MFMA kernels -- `value_other_conv_arithmetic` times the same step with them")
             try:   # measured, on this GPU, in this run: distance of every convolution arithmetic from a float64 convolution
                 g_ = torch.Generator(device=dev).manual_seed(77)
                 xe = torch.randn((1, 256, 24, 64), generator=g_, device=dev).contiguous(memory_format=torch.channels_last)
                 we = torch.randn((256, 256, 3, 3), generator=g_, device=dev) / 48.0
                 be = torch.randn((256,), generator=g_, device=dev)
                 want = torch.nn.functional.conv2d(xe.double(), we.double(), be.double(), padding=1)
-                chk = {"layer": "256 -> 256 channels, K = 2304, N(0,1) activations, outputs of magnitude ~5; error against float64 conv2d"}
+                chk = {}   # [max abs, rms] error on a 256 -> 256 layer (K = 2304, outputs ~5)
                 from c2m_amd import ops as _o
-                for name, algo in (("fp32_mfma_direct", "direct"), ("f16x2_three_products", "split16"), ("bf16x3_six_products", "split")):
+                for name, algo in (("fp32_mfma", "direct"), ("f16x2", "split16"), ("bf16x3", "split")):
                     d_ = (_o.conv3x3(xe, we, be, algo=algo).double() - want)
-                    chk[name] = {"max_abs": float(d_.abs().max()), "rms": float(d_.pow(2).mean().sqrt())}
-                line["conv_arithmetic_check"] = chk
+                    chk[name] = [float(f"{float(d_.abs().max()):.3g}"), float(f"{float(d_.pow(2).mean().sqrt()):.3g}")]
+                line["conv_error_vs_fp64"] = chk
             except Exception as e:  # noqa: BLE001 -- a diagnostic, never the reason a bench line is lost
-                line["conv_arithmetic_check"] = {"error": repr(e)}
+                line["conv_error_vs_fp64"] = {"error": repr(e)}
             if not args.no_alt:
-                # the same step on the other convolution arithmetics (outside the timed region of `value`)
+                # the same step on the other arithmetics (outside the timed region of `value`): strict fp32-MFMA convolutions +
+                # exact fp32 correlation sweep (no 16-bit pipe anywhere), and the bf16 x 3 convolution flavour
                 from c2m_amd import ops as _ops
-                alt = {}
-                for name, (s16, spl) in (("bf16x3_six_products", (False, _ops._SPLIT)), ("fp32_mfma_direct_winograd", (False, "0"))):
-                    keep = (_ops._SPLIT16, _ops._SPLIT)
-                    _ops._SPLIT16, _ops._SPLIT = s16, spl
-                    try:
+
+                def rerun(n_):
+                    it[0] = 0
+                    restore_step()
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(n_):
                         it[0] = 0
                         restore_step()
-                        sync()
-                        it[0] = 0
-                        t0 = time.perf_counter()
-                        for _ in range(min(args.steps, 5)):
-                            it[0] = 0
-                            restore_step()
-                        sync()
-                        alt[name] = B * world * min(args.steps, 5) / (time.perf_counter() - t0)
-                    finally:
-                        _ops._SPLIT16, _ops._SPLIT = keep
-                line["value_other_conv_arithmetic"] = alt
+                    sync()
+                    return B * world * n_ / (time.perf_counter() - t0)
+                n_alt = min(args.steps, 5)
+                keep = (_ops._SPLIT16, _ops._SPLIT)
+                try:
+                    _ops._SPLIT16, _ops._SPLIT = False, keep[1]
+                    line["value_bf16x3_convolutions"] = _rnd(rerun(n_alt), 2)
+                    _ops._SPLIT16, _ops._SPLIT = False, "0"
+                    with _ops.corr_filter_mode(0):
+                        line["value_strict_fp32_mfma"] = _rnd(rerun(n_alt), 2)
+                    _ops._SPLIT16, _ops._SPLIT = keep
+                    with _ops.corr_filter_mode(0):
+                        line["value_exact_corr_sweep"] = _rnd(rerun(n_alt), 2)
+                finally:
+                    _ops._SPLIT16, _ops._SPLIT = keep
         if world == 1 and not args.no_cpu_baseline and not bf16:
             idx_gpu = pre_timed.max_idx.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline_restore(ext, mp, net, lq, up, ref, sr, idx_gpu)

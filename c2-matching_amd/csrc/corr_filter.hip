@@ -360,20 +360,26 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     }
     code = code_nx;
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
-
+    // Row sums of the three taps of a patch row, formed in registers BEFORE barrier (B) (only the ring stores need it): lane
+    // (hi, j) holds D[pixel (2w+hi, r)][ref column j] in acc[r]; the value at (pixel column + 1, ref column + 1) is the next
+    // register shifted by one lane (DPP wave_shl:1):  H[r] = D[r] + shl(D[r+1] + shl(D[r+2]))   (oracle tap order)
     auto shl1 = [](float x) __attribute__((always_inline)) {
       return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
     };
+    float hh[TPQ];
     {
-      float dv[16], tt[16], hh[TPQ];
+      float dv[16], tt[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dv[r] = acc[r];
 #pragma unroll
       for (int r = 1; r < 15; ++r) tt[r] = dv[r] + shl1(dv[r + 1]);
 #pragma unroll
       for (int r = 0; r < TPQ; ++r) hh[r] = dv[r] + shl1(tt[r + 1]);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (B) every tap-sum that reads slab sl0 (about to be overwritten) is done
+    {
       float* dst = ring + sl0 * SLAB + store_off;
 #pragma unroll
       for (int r = 0; r < TPQ; ++r) dst[r * WT] = hh[r];
@@ -583,8 +589,8 @@ static int launch_filter_c(hipStream_t st, const _Float16* qpl, const _Float16* 
                            const float* sc, const float* band, const int2* skip, int* cnt, int* cand) {
   const int tiles_y = ceil_div(Hq - 2, TPQ), tiles_x = ceil_div(Wq - 2, TPQ);
   const size_t lds = sizeof(float) * (size_t)(3 * SLAB) + 2 * (size_t)C * 128;
-  // operand prefetch distance in k steps ($C2M_CORR_PF = 1 / 2: A/B measurement; 2 leaves no register to spare at C = 256)
-  static const int pf = [] { const char* e = getenv("C2M_CORR_PF"); return (e && e[0] == '1') ? 1 : 2; }();
+  // operand prefetch distance in k steps ($C2M_CORR_PF = 2: two steps ahead -- measured equal to one step on configs[2], 17.5 vs 17.6 ms, and it leaves no register to spare at C = 256)
+  static const int pf = [] { const char* e = getenv("C2M_CORR_PF"); return (e && e[0] == '2') ? 2 : 1; }();
   static unsigned long long lds_set[2] = {0, 0};
   auto kern = pf == 1 ? &corr_filter_kernel<C, 1> : &corr_filter_kernel<C, 2>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, lds_set[pf - 1])) return rc;

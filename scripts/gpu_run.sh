@@ -42,6 +42,15 @@ for stage in "$@"; do
                 cd $R
                 (python scripts/pmc_kernel.py $O/pmc_corr1 corr; python scripts/pmc_kernel.py $O/pmc_corr2 corr; python scripts/pmc_kernel.py $O/pmc_corr3 corr) > $O/pmc_corr_summary.txt 2>&1
                 rm -rf $O/pmc_corr1 $O/pmc_corr2 $O/pmc_corr3 ;;
+    abl_cycles) cd /tmp
+                for abl in 0 2 32 64 8 111 48 39; do
+                  C2M_SPLIT_ABL=$abl timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace -f csv -d $O/abl_$abl -o c -- python $R/scripts/bench_conv.py --algo split16 --only 'body 64->64 @640' --iters 6 > $O/abl_$abl.log 2>&1
+                  echo "=== C2M_SPLIT_ABL=$abl" >> $O/abl_cycles.txt
+                  grep "^{'layer" $O/abl_$abl.log >> $O/abl_cycles.txt
+                  python $R/scripts/pmc_kernel.py $O/abl_$abl conv3x3_split_kernel >> $O/abl_cycles.txt 2>&1
+                  rm -rf $O/abl_$abl
+                done
+                cd $R ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac

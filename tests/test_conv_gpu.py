@@ -562,3 +562,53 @@ def test_conv3x3_wgrad_and_dgrad_entry_points(ops, dev):
     F.conv2d(x64, w64, None, padding=1).backward(g.double().contiguous())
     assert float((gw.double() - w64.grad).abs().max()) < 1e-5 * float(w64.grad.abs().max())
     assert float((dx.double() - x64.grad).abs().max()) < 1e-5 * float(x64.grad.abs().max())
+
+
+def test_f16_range_guard_switches_a_module_to_bf16x3(ops, dev):
+    """The default f16 x 2 flavour covers |activation| < 65520.  A launch that meets a larger value raises the device flag
+    (c2m_conv3x3_desc.range_flag); a fused module forward then recomputes on bf16 x 3 (full fp32 range), warns once and
+    keeps that flavour -- a drop-in never returns NaN where the reference's nn.Conv2d stack (arch_util.py:80-136,
+    vgg_arch.py:107-145) returns a number."""
+    import warnings
+    from mmsr.models.archs.vgg_arch import VGGFeatureExtractor
+    # (1) the flag itself, at the ops level
+    x = _cl(_rand((1, 32, 8, 32), dev, 401))
+    w, b = _rand((32, 32, 3, 3), dev, 402, 0.06), _rand((32,), dev, 403)
+    flag = ops._range_flag(x.device)
+    flag.zero_()
+    ops.conv3x3(x, w, b, algo="split16")
+    assert int(flag.item()) == 0
+    xb = x.clone()
+    xb[0, 3, 2, 9] = -7.0e4
+    ops.conv3x3(xb, w, b, algo="split16")
+    assert int(flag.item()) == 1
+    # (2) a VGG tower fed an un-normalised 0..255-style image scaled far out of range
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        vgg = VGGFeatureExtractor(["relu1_1", "relu2_1", "relu3_1"], "vgg19", use_input_norm=False).to(dev).eval()
+    torch.manual_seed(5)
+    for m in vgg.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    img = torch.rand(1, 3, 40, 48, device=dev) * 6.0e4          # relu1_1 activations reach ~1e5 .. 1e6
+    ref = {}
+    vd = VGGFeatureExtractor(["relu1_1", "relu2_1", "relu3_1"], "vgg19", use_input_norm=False).double().eval()
+    vd.load_state_dict({k: v.double().cpu() for k, v in vgg.state_dict().items()})
+    with torch.no_grad():
+        ref = vd(img.double().cpu())
+        assert vgg._use_fused(img) and not getattr(vgg, "_c2m_conv_bf16x3", False)
+        with pytest.warns(RuntimeWarning, match="bf16 x 3"):
+            got = vgg(img)
+        assert vgg._c2m_conv_bf16x3 is True
+        for k, want in ref.items():
+            assert bool(torch.isfinite(got[k]).all()), k
+            scale = float(want.abs().max())
+            assert float((got[k].double().cpu() - want).abs().max()) <= 1e-5 * scale, k
+        assert max(float(v.abs().max()) for v in ref.values()) > 65520.0     # the input really left the f16 x 2 domain
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                        # pinned: no second warning, no f16 x 2 launch
+            again = vgg(img)
+        assert all(torch.equal(again[k], got[k]) for k in got)
+        small = vgg(torch.rand(1, 3, 40, 48, device=dev))         # stays on bf16 x 3 (finite either way)
+        assert all(bool(torch.isfinite(v).all()) for v in small.values())
