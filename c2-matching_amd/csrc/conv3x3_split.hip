@@ -396,8 +396,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       split3(v, cq[0], cq[1], cq[2]);
     } else if constexpr (FL == 2) {
       split2_f16(v, cq[0], cq[1]);
-      amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
-      amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+      // (asm volatile: these must read the raw registers BEFORE the volatile asm that re-loads them is issued -- the compiler
+      // does not know that load is asynchronous; plain C++ here was scheduled behind it and made it copy the load's
+      // destination registers before the data had arrived)
+      asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
+                   : "+v"(amax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
     } else {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 h;
