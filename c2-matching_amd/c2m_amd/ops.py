@@ -540,8 +540,9 @@ def f16_range_guard(owner, fn, device):
                 return fn()
         return fn()
     if torch.cuda.is_current_stream_capturing():
-        raise _lib.C2MError("f16_range_guard: the range check reads a flag back and cannot run inside a hipGraph capture; use "
-                            "ops.conv_flavour('bf16x3') (full fp32 range, no check) for captured inference")
+        # the range check reads a flag back, which a hipGraph capture cannot do: captured forwards run the full-range flavour
+        with conv_flavour("bf16x3"):
+            return fn()
     flag = _range_flag(device)
     flag.zero_()
     out = fn()

@@ -292,6 +292,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
+  // epilogue staging (MODE 0, whole-line stores): 4 KiB per wave.  f16 x 2 / bf16 x 3: inside the plane buffer the tile's last
+  // chunk has just left (free until the next chunk's split writes into it: one extra barrier per tile); bf16: its plane
+  // buffers are too small, the region follows the bias
+  constexpr unsigned EPI_BYTES = 4 * 4096;
+  static_assert(FL == 1 || PLB >= (int)EPI_BYTES, "staging tile must fit the plane buffer");
+  const unsigned epi_own = bias_lds + 256;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -702,10 +708,59 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
       } else {
+        bool stored = false;
+        if constexpr (MODE == 0 && !(ABL & 64)) {
+          // Whole-line stores: the accumulators (lane = pixel, 4 consecutive couts per register quad: a store instruction
+          // would touch 32 lines with 32 bytes each) go through a per-wave [32 pixels][32 couts] LDS tile and come back as
+          // lane = (pixel l >> 3 (+ 8r), cout quad l & 7): 8 lanes cover the 128 bytes a pixel owns in this cout tile.  The
+          // 16-byte column of (pixel, quad) is quad ^ (pixel & 7): conflict-free for the ds_write_b128 lane groups (8
+          // consecutive pixels, one quad) and the ds_read_b128 ones.  Residuals are fetched in the same whole-line layout.
+          if (p.out_vec4 && p.Cout % MW == 0) {
+            stored = true;
+            const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
+            const unsigned wl = epi + (unsigned)j * 128u + (unsigned)((hi ^ (j & 7)) << 4);
+            const unsigned rl = epi + (unsigned)(l >> 3) * 128u + (unsigned)(((l & 7) ^ ((l >> 3) & 7)) << 4);
+            typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+            const int cq = cb * MW + 4 * (l & 7);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int y = y0 + 2 * wv + nt;
+              const size_t orow = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                  f32x4 v;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+                  *(lds_f32x4*)(uintptr_t)(wl ^ (unsigned)(qd << 5)) = v;
+                }
+                f32x4 t[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int x = x0 + (l >> 3) + 8 * r;
+                  if (y < p.H && x < p.W) {
+                    const size_t o = orow + (size_t)x * p.out_pix_pitch + cq + mt * 32;
+                    f32x4 v = t[r];
+                    if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + o);
+                    if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + o);
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
+                  }
+                }
+              }
+            }
+            if constexpr (FL != 1) {   // the staging tiles live in a plane buffer: nobody may start splitting into it before all have read
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+            }
+          }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int y = y0 + 2 * wv + nt, x = x0 + j;
-          const bool pok = y < p.H && x < p.W;
+          const bool pok = y < p.H && x < p.W && !stored;
           if (!pok) continue;
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
@@ -820,7 +875,7 @@ int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
   constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + (NP != 3 ? 3 : 2) * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 +
-                          256;   // planes (x2 when pipelined), weight ring (3 / 2 slots), dummy, bias
+                          256 + (NP == 1 ? 4 * 4096 : 0);   // planes (x2 when pipelined), weight ring (3 / 2 slots), dummy, bias, bf16: staging
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {

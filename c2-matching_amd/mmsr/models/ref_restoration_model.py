@@ -47,6 +47,12 @@ class RefRestorationModel(BaseModel):
         # (one process, ONE device: nn.DataParallel's scatter / replicate / worker threads cannot be captured)
         self._graph_on = bool(self.is_train and (self.opt.get('train') or {}).get('hip_graph') and not self.opt.get('dist')
                               and self.device.type == 'cuda' and not isinstance(self.net_g, torch.nn.DataParallel))
+        if self._graph_on:
+            # the captured step cannot read the f16 x 2 range flag back (c2m_amd.ops.f16_range_guard): the frozen nets that run
+            # under no_grad inside it keep the full-range bf16 x 3 flavour from the first (eager) step on
+            for net in (self.net_extractor, self.net_map):
+                for m in net.modules():
+                    m._c2m_conv_bf16x3 = True
         self._eval_feed = False   # True while a validation loop feeds data: its batches bypass the graph's static buffers
         self._graph, self._graph_calls, self._static = None, 0, None
         if self.is_train:
