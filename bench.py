@@ -352,7 +352,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default 16; 4 for --workload train and --lr 320)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default 16; 4 for --lr 320; --workload train: "
+                                                             "--global-batch / world size)")
+    ap.add_argument("--global-batch", type=int, default=32,
+                    help="--workload train: pairs per step over ALL ranks (BASELINE configs[3]: 32); each rank takes global / world, "
+                         "which must divide (mmsr/data/__init__.py:70-73)")
     ap.add_argument("--lr", type=int, default=None, help="LR size = feature-map size (default 160; 40 for --workload train)")
     ap.add_argument("--workload", choices=("restore", "corr", "train"), default="restore")
     ap.add_argument("--graph", choices=("0", "1"), default="0",
@@ -390,7 +394,11 @@ def main():
     ops = c2m_amd.ops
     train = args.workload == "train"
     h = args.lr or (40 if train else 160)
-    B = args.batch or (4 if (train or h >= 320) else 16)
+    if train and args.batch is None:
+        from mmsr.data import per_rank_batch_size
+        B = per_rank_batch_size(args.global_batch, world)     # asserts global % world == 0 as the reference's dataloader does
+    else:
+        B = args.batch or (4 if h >= 320 else 16)
     C = 256
 
     def sync():
@@ -462,11 +470,20 @@ def main():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
             model = RefRestorationModel(opt)
-        g = torch.Generator().manual_seed(100 + rank)
-        gt = torch.rand((B, 3, 4 * h, 4 * h), generator=g)
+        # which synthetic pairs this rank trains on: the reference's rank partition (DistIterSampler, data_sampler.py:50-63) over
+        # a 4096-pair synthetic set -- every rank draws the same epoch permutation and keeps its stride-by-rank share
+        from mmsr.data import DistIterSampler
+        smp = DistIterSampler(range(4096), num_replicas=world, rank=rank, ratio=1)
+        mine = [i for _, i in zip(range(B), iter(smp))]
+
+        def pair(i):
+            g = torch.Generator().manual_seed(100000 + i)
+            return torch.rand((3, 4 * h, 4 * h), generator=g), torch.rand((3, 4 * h, 4 * h), generator=g)
+        pairs = [pair(i) for i in mine]
+        gt = torch.stack([a for a, _ in pairs])
         lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
         up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)
-        model.feed_data({"img_in_lq": lq, "img_ref": torch.rand((B, 3, 4 * h, 4 * h), generator=g), "img_in": gt, "img_in_up": up})
+        model.feed_data({"img_in_lq": lq, "img_ref": torch.stack([r for _, r in pairs]), "img_in": gt, "img_in_up": up})
         it = [0]
 
         def train_step():
@@ -476,8 +493,8 @@ def main():
 
         dt, kern, loss = timed(train_step)
         grad_bytes = sum(p.numel() * 4 for p in unwrap(model.net_g).parameters() if p.requires_grad)
-        line = dict(base, metric=METRIC + " -- stage-3 training step", value=B * world * args.steps / dt,
-                    ms_per_step=dt / args.steps * 1e3, dtype="f32",
+        line = dict(base, metric=METRIC + " -- stage-3 training step", value=_rnd(B * world * args.steps / dt, 3),
+                    ms_per_step=_rnd(dt / args.steps * 1e3, 3), dtype="f32", scaling="strong" if args.batch is None else "weak",
                     config={"workload": f"configs[3]: stage-3 MSE training step (extractor + correspondence under no_grad, RestorationNet "
                                         f"forward, L1 loss, backward incl. three DCNv2 backward passes, Adam with the reference's four "
                                         f"parameter groups), {B} pairs per GPU, GT {4*h}x{4*h} (LR {h}x{h}, Ref {4*h}x{4*h})",
@@ -486,7 +503,8 @@ def main():
                                                           "overlapped with backward)" if dist is not None else " (single process)")},
                     gradient_allreduce_bytes_per_step_per_gpu=grad_bytes if dist is not None else 0,
                     net_g_gradient_bytes=grad_bytes, loss=float(loss), hip_graph=bool(opt["train"]["hip_graph"]),
-                    c2m_kernel_ms_per_step={k: sum(v) / args.steps for k, v in kern.items()})
+                    train_kernels=os.environ.get("C2M_TRAIN_KERNELS", "auto"), pairs_of_this_rank=mine[:4] + ["..."],
+                    c2m_kernel_ms_per_step={k: _rnd(sum(v) / args.steps, 3) for k, v in kern.items()})
         return finish(line)
 
     # ---- configs[1] leg: correlation only on synthetic features (sub-record of the default line) --------------------

@@ -292,9 +292,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
-  // epilogue staging (MODE 0, whole-line stores): 4 KiB per wave.  f16 x 2 / bf16 x 3: inside the plane buffer the tile's last
+  // epilogue staging of the DCN head (MODE 3): 4 KiB per wave.  f16 x 2 / bf16 x 3: inside the plane buffer the tile's last
   // chunk has just left (free until the next chunk's split writes into it: one extra barrier per tile); bf16: its plane
-  // buffers are too small, the region follows the bias
+  // buffers are too small, the region follows the bias.  (The same staging for the channels-last mode -- whole 128-byte
+  // lines per pixel instead of 32-byte pieces of 32 lines -- was built and measured in round 4: 1.60 vs 1.53 ms on the 64 -> 64
+  // @640 layer, 114 vs 111 ms over a step.  What a store costs is its ISSUE, not the lines it touches: the staging only
+  // pays where it cuts the instruction count, i.e. for the dword-granular planar stores below.)
   constexpr unsigned EPI_BYTES = 4 * 4096;
   static_assert(FL == 1 || PLB >= (int)EPI_BYTES, "staging tile must fit the plane buffer");
   const unsigned epi_own = bias_lds + 256;
@@ -653,6 +656,84 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     } else if constexpr (MODE == 3) {
       float asum = 0.0f;
       const HeadOut ho = head_out(p, b);
+      const int l_ = l, cb_ = cb;
+      if ((p.W & 3) == 0) {
+        // Planar offset / mask maps, FOUR PIXELS PER LANE AND STORE: lane = pixel in the accumulators, so a planar store is one
+        // dword per lane and 64 instructions per wave and tile.  The head values (conv + bias + pre-offset, or sigmoid) go
+        // through a per-wave [32 channels][32 pixels] LDS tile and come back as lane = (channel l >> 3 (+ 8r), pixel quad
+        // l & 7): 16-byte stores, 8 lanes per 128-byte line, 16 instructions.  Invalid lanes store to the buffer's
+        // out-of-range offset (dropped by the hardware).
+        typedef __attribute__((address_space(3))) float lds_f32;
+        typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // (the lane id and the cout block are laundered through empty asm: everything derived from them below is then computed
+        // HERE, once per tile, instead of being hoisted in front of the main loop and carried across it in spilled registers)
+        int l = l_, cb = cb_;
+        asm volatile("" : "+v"(l), "+s"(cb));
+        const int hi = l >> 5, j = l & 31;
+        const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
+        const unsigned wl = epi + (unsigned)(4 * hi) * 128u + (unsigned)j * 4u;
+        const unsigned rl = epi + (unsigned)(l >> 3) * 128u + (unsigned)(l & 7) * 16u;
+        const int HWb = p.H * p.W * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int y = y0 + 2 * wv + nt, x = x0 + j;
+          const bool pok = y < p.H && x < p.W;
+          const int xq = x0 + 4 * (l & 7);
+          const unsigned vbase = (y < p.H && xq < p.W) ? (unsigned)((y * p.W + xq) * 4 + (l >> 3) * HWb) : kOOB;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const int col_u = cb * MW + mt * 32 + 8 * qd;        // slice channel of the quad pair (wave-uniform)
+              const int co_u = col_u + p.co_off, co = co_u + 4 * hi;
+              float val[4];
+              if (co_u < p.n_off) {   // (wave-uniform: n_off is a multiple of 8)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                  const int gt = (co >> 1) + h2, tap = gt % 9;
+                  const int ki = (tap * 11) >> 5, kj = tap - 3 * ki;
+                  float fy = 0.0f, fx = 0.0f;
+                  if (p.flow) {
+                    const int ys = y - (ki << p.scale_shift), xs = x - (kj << p.scale_shift);
+                    const int yy = ys >> p.scale_shift, xx = xs >> p.scale_shift;
+                    const bool ok = pok & (ys >= 0) & (xs >= 0) & (yy < p.fh) & (xx < p.fw);
+                    const float2 f = reinterpret_cast<const float2*>(p.flow)[(size_t)b * p.fh * p.fw + (ok ? yy * p.fw + xx : 0)];
+                    const float sc = ok ? (float)p.scale : 0.0f;
+                    fx = f.x * sc;
+                    fy = f.y * sc;
+                  }
+                  const float a0 = acc[mt][nt][4 * qd + 2 * h2], a1 = acc[mt][nt][4 * qd + 2 * h2 + 1];
+                  if (pok && col_u + 4 * hi + 2 * h2 < p.Cout) asum += fabsf(a0) + fabsf(a1);
+                  val[2 * h2] = a0 + fy;
+                  val[2 * h2 + 1] = a1 + fx;
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[mt][nt][4 * qd + e]));
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * qd + e) * 128)) = val[e];
+            }
+            f32x4 t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int col_u = cb * MW + mt * 32 + 8 * r;          // slice channel of row (l >> 3) = 0
+              const int co_u = col_u + p.co_off;
+              const unsigned vo = (col_u + (l >> 3) < p.Cout) ? vbase : kOOB;
+              const u32x4 d = __builtin_bit_cast(u32x4, t[r]);
+              if (co_u < p.n_off) __builtin_amdgcn_raw_buffer_store_b128(d, ho.off, vo, co_u * HWb, 0);
+              else __builtin_amdgcn_raw_buffer_store_b128(d, ho.msk, vo, (co_u - p.n_off) * HWb, 0);
+            }
+          }
+        }
+        if constexpr (FL != 1) {   // the staging tiles live in a plane buffer: nobody may split into it before all have read
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      } else {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int y = y0 + 2 * wv + nt, x = x0 + j;
@@ -668,6 +749,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
             asum += dcn_head_store(p, ho, b, y, x, col - 4 * hi, 4 * hi, v);
           }
+      }
       }
       if (p.abs_sum) {
 #pragma unroll
@@ -708,59 +790,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
       } else {
-        bool stored = false;
-        if constexpr (MODE == 0 && !(ABL & 64)) {
-          // Whole-line stores: the accumulators (lane = pixel, 4 consecutive couts per register quad: a store instruction
-          // would touch 32 lines with 32 bytes each) go through a per-wave [32 pixels][32 couts] LDS tile and come back as
-          // lane = (pixel l >> 3 (+ 8r), cout quad l & 7): 8 lanes cover the 128 bytes a pixel owns in this cout tile.  The
-          // 16-byte column of (pixel, quad) is quad ^ (pixel & 7): conflict-free for the ds_write_b128 lane groups (8
-          // consecutive pixels, one quad) and the ds_read_b128 ones.  Residuals are fetched in the same whole-line layout.
-          if (p.out_vec4 && p.Cout % MW == 0) {
-            stored = true;
-            const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
-            const unsigned wl = epi + (unsigned)j * 128u + (unsigned)((hi ^ (j & 7)) << 4);
-            const unsigned rl = epi + (unsigned)(l >> 3) * 128u + (unsigned)(((l & 7) ^ ((l >> 3) & 7)) << 4);
-            typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-            const int cq = cb * MW + 4 * (l & 7);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const int y = y0 + 2 * wv + nt;
-              const size_t orow = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch;
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                  f32x4 v;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
-                  *(lds_f32x4*)(uintptr_t)(wl ^ (unsigned)(qd << 5)) = v;
-                }
-                f32x4 t[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int x = x0 + (l >> 3) + 8 * r;
-                  if (y < p.H && x < p.W) {
-                    const size_t o = orow + (size_t)x * p.out_pix_pitch + cq + mt * 32;
-                    f32x4 v = t[r];
-                    if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + o);
-                    if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                    *reinterpret_cast<f32x4*>(p.out + o) = v;
-                  }
-                }
-              }
-            }
-            if constexpr (FL != 1) {   // the staging tiles live in a plane buffer: nobody may start splitting into it before all have read
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              __builtin_amdgcn_s_barrier();
-            }
-          }
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int y = y0 + 2 * wv + nt, x = x0 + j;
-          const bool pok = y < p.H && x < p.W && !stored;
+          const bool pok = y < p.H && x < p.W;
           if (!pok) continue;
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;

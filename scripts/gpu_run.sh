@@ -21,6 +21,9 @@ for stage in "$@"; do
     bench_quick) timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_quick.log 2>&1; echo "rc=$?" >> $O/bench_quick.log ;;
     bench_corr) timeout 300 python bench.py --workload corr --steps 10 --warmup 3 > $O/bench_corr.log 2>&1 ;;
     bench_train) timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.log 2>&1
+                C2M_TRAIN_KERNELS=0 timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train_stock.log 2>&1
+                timeout 300 python bench.py --workload train --batch 4 --steps 20 --warmup 5 > $O/bench_train_b4.log 2>&1
+                C2M_TRAIN_KERNELS=0 timeout 300 python bench.py --workload train --batch 4 --steps 20 --warmup 5 > $O/bench_train_b4_stock.log 2>&1
                 C2M_TRAIN_KERNELS=1 timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train_kernels.log 2>&1
                 C2M_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload train --steps 10 --warmup 3 > $O/bench_train_rccl_1rank.log 2>&1 ;;
     bench_cfg5) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 > $O/bench_cfg5_bf16.log 2>&1
