@@ -656,8 +656,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     } else if constexpr (MODE == 3) {
       float asum = 0.0f;
       const HeadOut ho = head_out(p, b);
-      const int l_ = l, cb_ = cb;
-      if ((p.W & 3) == 0) {
+      const int l_ = l;
+      if (p.out_vec4) {   // (mode 3: set by launch_split -- W % 4 == 0 and not $C2M_HEAD_WIDE=0)
         // Planar offset / mask maps, FOUR PIXELS PER LANE AND STORE: lane = pixel in the accumulators, so a planar store is one
         // dword per lane and 64 instructions per wave and tile.  The head values (conv + bias + pre-offset, or sigmoid) go
         // through a per-wave [32 channels][32 pixels] LDS tile and come back as lane = (channel l >> 3 (+ 8r), pixel quad
@@ -666,10 +666,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
         typedef __attribute__((address_space(3))) float lds_f32;
         typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        // (the lane id and the cout block are laundered through empty asm: everything derived from them below is then computed
+        // (the lane id is laundered through an empty asm: everything derived from it below is then computed
         // HERE, once per tile, instead of being hoisted in front of the main loop and carried across it in spilled registers)
-        int l = l_, cb = cb_;
-        asm volatile("" : "+v"(l), "+s"(cb));
+        int l = l_;
+        asm volatile("" : "+v"(l));
         const int hi = l >> 5, j = l & 31;
         const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
         const unsigned wl = epi + (unsigned)(4 * hi) * 128u + (unsigned)j * 4u;
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int col_u = cb * MW + mt * 32 + 8 * r;          // slice channel of row (l >> 3) = 0
-              const int co_u = col_u + p.co_off;
+              const int co_u = __builtin_amdgcn_readfirstlane(col_u + p.co_off);   // (wave-uniform: scalar offset, no waterfall)
               const unsigned vo = (col_u + (l >> 3) < p.Cout) ? vbase : kOOB;
               const u32x4 d = __builtin_bit_cast(u32x4, t[r]);
               if (co_u < p.n_off) __builtin_amdgcn_raw_buffer_store_b128(d, ho.off, vo, co_u * HWb, 0);
@@ -958,6 +958,10 @@ int launch_split(hipStream_t st, Params p, int np) {
   p.tiles_x = ceil_div(p.W, split::TWX);
   p.tiles_y = ceil_div(p.H, split::THY);
   p.nchunks = p.Cin / split::KC;
+  if (p.out_mode == 3) {   // DCN head: 16-byte planar stores (four pixels per lane) need rows of whole 16-byte groups
+    static const int wide = [] { const char* e = getenv("C2M_HEAD_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.out_vec4 = (wide && p.W % 4 == 0) ? 1 : 0;
+  }
   const int MT = p.Cout <= 32 ? 1 : 2, MW = 32 * MT;
   const int ncb = ceil_div(p.Cout, MW);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
