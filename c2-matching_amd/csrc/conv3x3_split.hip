@@ -790,10 +790,50 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
       } else {
+        bool stored = false;
+        if constexpr (MODE == 2) {
+          // planar [B][Cout][H][W]: four pixels per lane and store through the per-wave LDS tile, as the DCN head above
+          // (16 instead of 64 store instructions per wave and tile)
+          if (p.out_vec4) {   // (mode 2: set by launch_split -- W % 4 == 0, 16-byte aligned base, not $C2M_HEAD_WIDE=0)
+            stored = true;
+            typedef __attribute__((address_space(3))) float lds_f32;
+            typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+            int ll = l;
+            asm volatile("" : "+v"(ll));
+            const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
+            const unsigned wl = epi + (unsigned)(4 * (ll >> 5)) * 128u + (unsigned)(ll & 31) * 4u;
+            const unsigned rl = epi + (unsigned)(ll >> 3) * 128u + (unsigned)(ll & 7) * 16u;
+            const size_t HWs = (size_t)p.H * p.W;
+            const int xq = x0 + 4 * (ll & 7);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int y = y0 + 2 * wv + nt;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * (r >> 2) + (r & 3)) * 128)) = acc[mt][nt][r];
+                f32x4 t[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int co = cb * MW + mt * 32 + 8 * r + (ll >> 3);
+                  if (co < p.Cout && y < p.H && xq < p.W)
+                    *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.Cout + co) * HWs + (size_t)y * p.W + xq) = t[r];
+                }
+              }
+            }
+            if constexpr (FL != 1) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+            }
+          }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int y = y0 + 2 * wv + nt, x = x0 + j;
-          const bool pok = y < p.H && x < p.W;
+          const bool pok = y < p.H && x < p.W && !stored;
           if (!pok) continue;
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
@@ -961,6 +1001,9 @@ int launch_split(hipStream_t st, Params p, int np) {
   if (p.out_mode == 3) {   // DCN head: 16-byte planar stores (four pixels per lane) need rows of whole 16-byte groups
     static const int wide = [] { const char* e = getenv("C2M_HEAD_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
     p.out_vec4 = (wide && p.W % 4 == 0) ? 1 : 0;
+  } else if (p.out_mode == 2) {   // planar output: the same staging
+    static const int wide = [] { const char* e = getenv("C2M_HEAD_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.out_vec4 = (wide && p.W % 4 == 0 && reinterpret_cast<uintptr_t>(p.out) % 16 == 0) ? 1 : 0;
   }
   const int MT = p.Cout <= 32 ? 1 : 2, MW = 32 * MT;
   const int ncb = ceil_div(p.Cout, MW);
