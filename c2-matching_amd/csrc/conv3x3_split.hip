@@ -715,9 +715,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * qd + e) * 128)) = val[e];
             }
+            // (compiler fence: the dword stores above and the 16-byte loads below have different types -- without it the
+            // type-based alias analysis let some loads overtake the stores they read: 160 wrong offsets of 3.7 M)
+            asm volatile("" ::: "memory");
             f32x4 t[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int col_u = cb * MW + mt * 32 + 8 * r;          // slice channel of row (l >> 3) = 0
@@ -813,9 +817,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                   *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * (r >> 2) + (r & 3)) * 128)) = acc[mt][nt][r];
+                asm volatile("" ::: "memory");   // (stores and loads of different types: keep them in order, see the DCN head)
                 f32x4 t[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int co = cb * MW + mt * 32 + 8 * r + (ll >> 3);
