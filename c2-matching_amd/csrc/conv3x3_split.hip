@@ -715,9 +715,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * qd + e) * 128)) = val[e];
             }
-            // (compiler fence: the dword stores above and the 16-byte loads below have different types -- without it the
-            // type-based alias analysis let some loads overtake the stores they read: 160 wrong offsets of 3.7 M)
-            asm volatile("" ::: "memory");
+            // (the dword stores above must have LANDED before other lanes' 16-byte loads below read them)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x4 t[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
@@ -817,7 +816,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                   *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * (r >> 2) + (r & 3)) * 128)) = acc[mt][nt][r];
-                asm volatile("" ::: "memory");   // (stores and loads of different types: keep them in order, see the DCN head)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (as in the DCN head)
                 f32x4 t[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);

@@ -36,3 +36,8 @@ for k in res["0"]:
     if d.numel() > 1 and float(d.max()) > 0:
         idx = (d > 0).nonzero()
         print("   first mismatches", idx[:6].tolist(), "channels with mismatch", sorted(set(idx[:, 1].tolist()))[:40])
+        print("   ys", sorted(set(idx[:, 2].tolist())), "xs", sorted(set(idx[:, 3].tolist())))
+        for i in idx[:12].tolist():
+            bb, c, y, x = i
+            print("   ", i, "old", float(a[bb, c, y, x]), "new", float(b[bb, c, y, x]), "old nbrs c-1/c+1", float(a[bb, c - 1, y, x]), float(a[bb, c + 1, y, x]),
+                  "old x-16", float(a[bb, c, y, x - 16]), "old raw diff", float(b[bb, c, y, x] - a[bb, c, y, x]))
