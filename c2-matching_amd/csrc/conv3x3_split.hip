@@ -724,11 +724,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int col_u = cb * MW + mt * 32 + 8 * r;          // slice channel of row (l >> 3) = 0
-              const int co_u = __builtin_amdgcn_readfirstlane(col_u + p.co_off);   // (wave-uniform: scalar offset, no waterfall)
-              const unsigned vo = (col_u + (l >> 3) < p.Cout) ? vbase : kOOB;
+              const int co_u = __builtin_amdgcn_readfirstlane(col_u + p.co_off);   // (wave-uniform)
+              // The channel offset goes into the VECTOR offset, soffset stays 0: a 16-byte buffer store with a register
+              // soffset, followed at once by a VALU write of its data registers (the next quad's flow index), stored that
+              // index for the last four lanes of each 16-lane group -- on a busy CU only (two workgroups resident): the
+              // store-data hazard hipcc only guards when soffset is NOT a register (round 4: 160-6000 wrong offsets per map)
+              const bool isoff = co_u < p.n_off;
+              const unsigned vo = (col_u + (l >> 3) < p.Cout) ? vbase + (unsigned)((isoff ? co_u : co_u - p.n_off) * HWb) : kOOB;
               const u32x4 d = __builtin_bit_cast(u32x4, t[r]);
-              if (co_u < p.n_off) __builtin_amdgcn_raw_buffer_store_b128(d, ho.off, vo, co_u * HWb, 0);
-              else __builtin_amdgcn_raw_buffer_store_b128(d, ho.msk, vo, (co_u - p.n_off) * HWb, 0);
+              if (isoff) __builtin_amdgcn_raw_buffer_store_b128(d, ho.off, vo, 0, 0);
+              else __builtin_amdgcn_raw_buffer_store_b128(d, ho.msk, vo, 0, 0);
             }
           }
         }

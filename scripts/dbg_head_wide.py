@@ -9,15 +9,19 @@ from c2m_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 out = {}
-for (B, Cin, H, W, scale) in ((1, 64, 160, 160, 4), (1, 256, 40, 40, 1), (2, 128, 80, 80, 2), (1, 64, 24, 36, 4)):
+for (B, Cin, H, W, scale, fmode) in ((1, 64, 160, 160, 4, "rand"), (1, 64, 160, 160, 4, "none"), (1, 64, 320, 320, 4, "rand")):
     x = torch.randn((B, Cin, H, W), generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn((216, Cin, 3, 3), generator=g, device=dev) * 0.02
     b = torch.randn((216,), generator=g, device=dev) * 0.1
     fh, fw = H // scale - 2, W // scale - 2
     flow = torch.randint(-20, 20, (B, fh, fw, 2), generator=g, device=dev).float()
+    if fmode == "zero": flow = flow * 0
+    if fmode == "const": flow = flow * 0 + 7.0
+    if fmode == "none": flow = None
     ab = torch.zeros(256, dtype=torch.float64, device=dev)
     off, msk = ops.conv3x3_dcn_head(x, w, b, 8, flow, scale, ab)
-    out[(B, Cin, H, W, "off")] = off.cpu(); out[(B, Cin, H, W, "msk")] = msk.cpu(); out[(B, Cin, H, W, "abs")] = ab.sum().cpu()
+    out[(B, Cin, H, W, scale, fmode, "off")] = off.cpu(); out[(B, Cin, H, W, scale, fmode, "msk")] = msk.cpu()
+    continue
     w3 = torch.randn((3, 32, 3, 3), generator=g, device=dev) * 0.05
     x3 = torch.randn((B, 32, H, W), generator=g, device=dev).contiguous(memory_format=torch.channels_last)
     out[(B, Cin, H, W, "nchw3")] = ops.conv3x3(x3, w3, None, out_mode="nchw").cpu()
@@ -29,10 +33,10 @@ for wide in ("0", "1"):
     f = f"/tmp/dbg_wide_{wide}.pt"
     subprocess.check_call([sys.executable, "-c", CODE, f], env=dict(os.environ, C2M_HEAD_WIDE=wide))
     res[wide] = torch.load(f)
-for k in res["0"]:
-    a, b = res["0"][k], res["1"][k]
+for k, wide in [(k, w) for w in ("1",) for k in res["0"]]:
+    a, b = res["0"][k], res[wide][k]
     d = (a.double() - b.double()).abs()
-    print(k, "max diff", float(d.max()), "n diff", int((d > 0).sum()), "of", d.numel())
+    print("wide", wide, k, "max diff", float(d.max()), "n diff", int((d > 0).sum()), "of", d.numel())
     if d.numel() > 1 and float(d.max()) > 0:
         idx = (d > 0).nonzero()
         print("   first mismatches", idx[:6].tolist(), "channels with mismatch", sorted(set(idx[:, 1].tolist()))[:40])
