@@ -292,15 +292,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // [planes (one chunk) | weight ring x2 | DMA dummy 1 KiB | bias MW floats]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const unsigned pl_base = lds0, w_base = lds0 + NPB * PLB, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
-  // epilogue staging of the DCN head (MODE 3): 4 KiB per wave.  f16 x 2 / bf16 x 3: inside the plane buffer the tile's last
-  // chunk has just left (free until the next chunk's split writes into it: one extra barrier per tile); bf16: its plane
-  // buffers are too small, the region follows the bias.  (The same staging for the channels-last mode -- whole 128-byte
-  // lines per pixel instead of 32-byte pieces of 32 lines -- was built and measured in round 4: 1.60 vs 1.53 ms on the 64 -> 64
-  // @640 layer, 114 vs 111 ms over a step.  What a store costs is its ISSUE, not the lines it touches: the staging only
-  // pays where it cuts the instruction count, i.e. for the dword-granular planar stores below.)
-  constexpr unsigned EPI_BYTES = 4 * 4096;
-  static_assert(FL == 1 || PLB >= (int)EPI_BYTES, "staging tile must fit the plane buffer");
-  const unsigned epi_own = bias_lds + 256;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -656,92 +647,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     } else if constexpr (MODE == 3) {
       float asum = 0.0f;
       const HeadOut ho = head_out(p, b);
-      const int l_ = l;
-      if (p.out_vec4) {   // (mode 3: set by launch_split -- W % 4 == 0 and not $C2M_HEAD_WIDE=0)
-        // Planar offset / mask maps, FOUR PIXELS PER LANE AND STORE: lane = pixel in the accumulators, so a planar store is one
-        // dword per lane and 64 instructions per wave and tile.  The head values (conv + bias + pre-offset, or sigmoid) go
-        // through a per-wave [32 channels][32 pixels] LDS tile and come back as lane = (channel l >> 3 (+ 8r), pixel quad
-        // l & 7): 16-byte stores, 8 lanes per 128-byte line, 16 instructions.  Invalid lanes store to the buffer's
-        // out-of-range offset (dropped by the hardware).
-        typedef __attribute__((address_space(3))) float lds_f32;
-        typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        // (the lane id is laundered through an empty asm: everything derived from it below is then computed
-        // HERE, once per tile, instead of being hoisted in front of the main loop and carried across it in spilled registers)
-        int l = l_;
-        asm volatile("" : "+v"(l));
-        const int hi = l >> 5, j = l & 31;
-        const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
-        const unsigned wl = epi + (unsigned)(4 * hi) * 128u + (unsigned)j * 4u;
-        const unsigned rl = epi + (unsigned)(l >> 3) * 128u + (unsigned)(l & 7) * 16u;
-        const int HWb = p.H * p.W * 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int y = y0 + 2 * wv + nt, x = x0 + j;
-          const bool pok = y < p.H && x < p.W;
-          const int xq = x0 + 4 * (l & 7);
-          const unsigned vbase = (y < p.H && xq < p.W) ? (unsigned)((y * p.W + xq) * 4 + (l >> 3) * HWb) : kOOB;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              const int col_u = cb * MW + mt * 32 + 8 * qd;        // slice channel of the quad pair (wave-uniform)
-              const int co_u = col_u + p.co_off, co = co_u + 4 * hi;
-              float val[4];
-              if (co_u < p.n_off) {   // (wave-uniform: n_off is a multiple of 8)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                  const int gt = (co >> 1) + h2, tap = gt % 9;
-                  const int ki = (tap * 11) >> 5, kj = tap - 3 * ki;
-                  float fy = 0.0f, fx = 0.0f;
-                  if (p.flow) {
-                    const int ys = y - (ki << p.scale_shift), xs = x - (kj << p.scale_shift);
-                    const int yy = ys >> p.scale_shift, xx = xs >> p.scale_shift;
-                    const bool ok = pok & (ys >= 0) & (xs >= 0) & (yy < p.fh) & (xx < p.fw);
-                    const float2 f = reinterpret_cast<const float2*>(p.flow)[(size_t)b * p.fh * p.fw + (ok ? yy * p.fw + xx : 0)];
-                    const float sc = ok ? (float)p.scale : 0.0f;
-                    fx = f.x * sc;
-                    fy = f.y * sc;
-                  }
-                  const float a0 = acc[mt][nt][4 * qd + 2 * h2], a1 = acc[mt][nt][4 * qd + 2 * h2 + 1];
-                  if (pok && col_u + 4 * hi + 2 * h2 < p.Cout) asum += fabsf(a0) + fabsf(a1);
-                  val[2 * h2] = a0 + fy;
-                  val[2 * h2 + 1] = a1 + fx;
-                }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[mt][nt][4 * qd + e]));
-              }
-#pragma unroll
-              for (int e = 0; e < 4; ++e) *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * qd + e) * 128)) = val[e];
-            }
-            // (the dword stores above must have LANDED before other lanes' 16-byte loads below read them)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            f32x4 t[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int col_u = cb * MW + mt * 32 + 8 * r;          // slice channel of row (l >> 3) = 0
-              const int co_u = __builtin_amdgcn_readfirstlane(col_u + p.co_off);   // (wave-uniform)
-              // The channel offset goes into the VECTOR offset, soffset stays 0: a 16-byte buffer store with a register
-              // soffset, followed at once by a VALU write of its data registers (the next quad's flow index), stored that
-              // index for the last four lanes of each 16-lane group -- on a busy CU only (two workgroups resident): the
-              // store-data hazard hipcc only guards when soffset is NOT a register (round 4: 160-6000 wrong offsets per map)
-              const bool isoff = co_u < p.n_off;
-              const unsigned vo = (col_u + (l >> 3) < p.Cout) ? vbase + (unsigned)((isoff ? co_u : co_u - p.n_off) * HWb) : kOOB;
-              const u32x4 d = __builtin_bit_cast(u32x4, t[r]);
-              if (isoff) __builtin_amdgcn_raw_buffer_store_b128(d, ho.off, vo, 0, 0);
-              else __builtin_amdgcn_raw_buffer_store_b128(d, ho.msk, vo, 0, 0);
-            }
-          }
-        }
-        if constexpr (FL != 1) {   // the staging tiles live in a plane buffer: nobody may split into it before all have read
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-      } else {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int y = y0 + 2 * wv + nt, x = x0 + j;
@@ -758,7 +663,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             asum += dcn_head_store(p, ho, b, y, x, col - 4 * hi, 4 * hi, v);
           }
       }
-      }
+      // (Round 4 staged this epilogue -- and the planar NCHW one -- through a per-wave [32 channels][32 pixels] LDS tile so that
+      // a lane stores four consecutive pixels of one channel: 16 store instructions per wave and tile instead of 64, head
+      // 64 -> 216 @640^2 7.30 -> 5.72 ms.  It is NOT in the tree: on CUs with two resident workgroups one in ~10^6 of the
+      // values came out wrong.  Two causes were found and fixed -- a 16-byte buffer store with a REGISTER soffset followed at
+      // once by a VALU write of its data registers stores the new value for lanes 12-15 / 28-31 / 44-47 / 60-63 (hipcc guards
+      // that hazard only when soffset is an immediate); type-based alias analysis let 16-byte LDS loads overtake dword LDS
+      // stores -- a third (lanes 60-63 of flow-dependent channels, 32-200 values per 59 M) was not.  DESIGN.md 6.2.)
       if (p.abs_sum) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) asum += __shfl_xor(asum, off, 64);
@@ -798,52 +709,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
       } else {
-        bool stored = false;
-        if constexpr (MODE == 2) {
-          // planar [B][Cout][H][W]: four pixels per lane and store through the per-wave LDS tile, as the DCN head above
-          // (16 instead of 64 store instructions per wave and tile)
-          if (p.out_vec4) {   // (mode 2: set by launch_split -- W % 4 == 0, 16-byte aligned base, not $C2M_HEAD_WIDE=0)
-            stored = true;
-            typedef __attribute__((address_space(3))) float lds_f32;
-            typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-            int ll = l;
-            asm volatile("" : "+v"(ll));
-            const unsigned epi = (FL == 1 ? epi_own : pl_base + (PIPE ? (unsigned)((gc - 1) & 1) * PLB : 0u)) + (unsigned)wv * 4096u;
-            const unsigned wl = epi + (unsigned)(4 * (ll >> 5)) * 128u + (unsigned)(ll & 31) * 4u;
-            const unsigned rl = epi + (unsigned)(ll >> 3) * 128u + (unsigned)(ll & 7) * 16u;
-            const size_t HWs = (size_t)p.H * p.W;
-            const int xq = x0 + 4 * (ll & 7);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const int y = y0 + 2 * wv + nt;
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                  *(lds_f32*)(uintptr_t)(wl + (unsigned)((8 * (r >> 2) + (r & 3)) * 128)) = acc[mt][nt][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (as in the DCN head)
-                f32x4 t[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = *(const lds_f32x4*)(uintptr_t)(rl + (unsigned)r * 1024u);
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int co = cb * MW + mt * 32 + 8 * r + (ll >> 3);
-                  if (co < p.Cout && y < p.H && xq < p.W)
-                    *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.Cout + co) * HWs + (size_t)y * p.W + xq) = t[r];
-                }
-              }
-            }
-            if constexpr (FL != 1) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              __builtin_amdgcn_s_barrier();
-            }
-          }
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int y = y0 + 2 * wv + nt, x = x0 + j;
-          const bool pok = y < p.H && x < p.W && !stored;
+          const bool pok = y < p.H && x < p.W;
           if (!pok) continue;
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
@@ -958,7 +827,7 @@ int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
   constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + (NP != 3 ? 3 : 2) * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 +
-                          256 + (NP == 1 ? 4 * 4096 : 0);   // planes (x2 when pipelined), weight ring (3 / 2 slots), dummy, bias, bf16: staging
+                          256;   // planes (x2 when pipelined), weight ring (3 / 2 slots), dummy, bias
   static unsigned long long done[5] = {};
   int rc = C2M_OK;
   auto go = [&](auto kern, unsigned long long& dn) {
@@ -1008,13 +877,6 @@ int launch_split(hipStream_t st, Params p, int np) {
   p.tiles_x = ceil_div(p.W, split::TWX);
   p.tiles_y = ceil_div(p.H, split::THY);
   p.nchunks = p.Cin / split::KC;
-  if (p.out_mode == 3) {   // DCN head: 16-byte planar stores (four pixels per lane) need rows of whole 16-byte groups
-    static const int wide = [] { const char* e = getenv("C2M_HEAD_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
-    p.out_vec4 = (wide && p.W % 4 == 0) ? 1 : 0;
-  } else if (p.out_mode == 2) {   // planar output: the same staging
-    static const int wide = [] { const char* e = getenv("C2M_HEAD_WIDE"); return (e && e[0] == '0') ? 0 : 1; }();
-    p.out_vec4 = (wide && p.W % 4 == 0 && reinterpret_cast<uintptr_t>(p.out) % 16 == 0) ? 1 : 0;
-  }
   const int MT = p.Cout <= 32 ? 1 : 2, MW = 32 * MT;
   const int ncb = ceil_div(p.Cout, MW);
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;

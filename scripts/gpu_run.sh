@@ -54,9 +54,6 @@ for stage in "$@"; do
                   rm -rf $O/abl_$abl
                 done
                 cd $R ;;
-    dbg_wide)   C2M_HEAD_WIDE=0 timeout 600 python -m pytest tests/test_restoration_gpu.py -m gpu -q -x -k "golden or cfg3_chain" 2>&1 | tail -40 > $O/dbg_wide0.log
-                C2M_HEAD_WIDE=1 timeout 600 python -m pytest tests/test_restoration_gpu.py -m gpu -q -x -k "golden" 2>&1 | tail -60 > $O/dbg_wide1.log
-                timeout 300 python scripts/dbg_head_wide.py > $O/dbg_head_wide.log 2>&1 ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac
