@@ -534,6 +534,8 @@ class conv_flavour:
 def f16_range_guard(owner, fn, device):
     """Run `fn()` (a fused forward made of conv3x3 calls) so that it never returns f16 x 2 overflow garbage: see above.
     `owner` (an nn.Module or any object) remembers the pinned flavour in `owner._c2m_conv_bf16x3`."""
+    if getattr(_tls, "guarded", False):      # an enclosing guard (a parent module's forward) checks the flag for all of us
+        return fn()
     if getattr(owner, "_c2m_conv_bf16x3", False) or not _split16_now() or bf16_autocast():
         if getattr(owner, "_c2m_conv_bf16x3", False):
             with conv_flavour("bf16x3"):
@@ -545,7 +547,11 @@ def f16_range_guard(owner, fn, device):
             return fn()
     flag = _range_flag(device)
     flag.zero_()
-    out = fn()
+    _tls.guarded = True
+    try:
+        out = fn()
+    finally:
+        _tls.guarded = False
     if int(flag.item()) == 0:
         return out
     import warnings

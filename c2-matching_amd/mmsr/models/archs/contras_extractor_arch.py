@@ -36,5 +36,11 @@ class ContrasExtractorSep(nn.Module):
         self.feature_extraction_image2 = ContrasExtractorLayer()
 
     def forward(self, image1, image2):
-        return {'dense_features1': self.feature_extraction_image1(image1),
-                'dense_features2': self.feature_extraction_image2(image2)}
+        def both():
+            return {'dense_features1': self.feature_extraction_image1(image1),
+                    'dense_features2': self.feature_extraction_image2(image2)}
+        if not torch.is_grad_enabled() and image1.is_cuda and image1.dtype == torch.float32:
+            # one f16 x 2 range check (one 4-byte read-back) for both towers instead of one each
+            from c2m_amd import ops as _ops
+            return _ops.f16_range_guard(self, both, image1.device)
+        return both()

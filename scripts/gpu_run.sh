@@ -45,6 +45,17 @@ for stage in "$@"; do
                 cd $R
                 (python scripts/pmc_kernel.py $O/pmc_corr1 corr; python scripts/pmc_kernel.py $O/pmc_corr2 corr; python scripts/pmc_kernel.py $O/pmc_corr3 corr) > $O/pmc_corr_summary.txt 2>&1
                 rm -rf $O/pmc_corr1 $O/pmc_corr2 $O/pmc_corr3 ;;
+    pmc_cfg5)   cd /tmp
+                timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc5_fetch -o s -- python $R/bench.py --lr 320 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc5_fetch.log 2>&1
+                timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $O/pmc5_write -o s -- python $R/bench.py --lr 320 --dtype bf16 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc5_write.log 2>&1
+                cd $R
+                (python scripts/pmc_kernel.py $O/pmc5_fetch c2m; python scripts/pmc_kernel.py $O/pmc5_write c2m) > $O/pmc_cfg5_summary.txt 2>&1
+                rm -rf $O/pmc5_fetch $O/pmc5_write ;;
+    pmc_train)  cd /tmp
+                timeout 400 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -f csv -d $O/pmct -o s -- python $R/bench.py --workload train --batch 4 --steps 3 --warmup 2 > $O/pmct.log 2>&1
+                cd $R
+                python scripts/pmc_kernel.py $O/pmct "" > $O/pmc_train_summary.txt 2>&1
+                rm -rf $O/pmct ;;
     abl_cycles) cd /tmp
                 for abl in 0 2 32 64 8 111 48 39; do
                   C2M_SPLIT_ABL=$abl timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace -f csv -d $O/abl_$abl -o c -- python $R/scripts/bench_conv.py --algo split16 --only 'body 64->64 @640' --iters 6 > $O/abl_$abl.log 2>&1
