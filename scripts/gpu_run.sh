@@ -28,6 +28,9 @@ for stage in "$@"; do
                 C2M_BENCH_FORCE_DIST=1 timeout 300 python bench.py --workload train --steps 10 --warmup 3 > $O/bench_train_rccl_1rank.log 2>&1 ;;
     bench_cfg5) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 > $O/bench_cfg5_bf16.log 2>&1
                 timeout 300 python bench.py --lr 320 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_f32.log 2>&1 ;;
+    bench_cfg5_bf16) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16.log 2>&1
+                C2M_BF16_IO=0 timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16_f32io.log 2>&1 ;;
+    test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;
     prof)       cd /tmp
@@ -52,10 +55,12 @@ for stage in "$@"; do
                 (python scripts/pmc_kernel.py $O/pmc5_fetch c2m; python scripts/pmc_kernel.py $O/pmc5_write c2m) > $O/pmc_cfg5_summary.txt 2>&1
                 rm -rf $O/pmc5_fetch $O/pmc5_write ;;
     pmc_train)  cd /tmp
-                timeout 400 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -f csv -d $O/pmct -o s -- python $R/bench.py --workload train --batch 4 --steps 3 --warmup 2 > $O/pmct.log 2>&1
+                for c in FETCH_SIZE WRITE_SIZE; do   # (one counter per pass: both together exceed what the hardware collects)
+                  timeout 400 rocprofv3 --pmc $c --kernel-trace -f csv -d $O/pmct_$c -o s -- python $R/bench.py --workload train --global-batch 4 --steps 3 --warmup 2 > $O/pmct_$c.log 2>&1
+                done
                 cd $R
-                python scripts/pmc_kernel.py $O/pmct "" > $O/pmc_train_summary.txt 2>&1
-                rm -rf $O/pmct ;;
+                (python scripts/pmc_kernel.py $O/pmct_FETCH_SIZE ""; python scripts/pmc_kernel.py $O/pmct_WRITE_SIZE "") > $O/pmc_train_summary.txt 2>&1
+                rm -rf $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE ;;
     abl_cycles) cd /tmp
                 for abl in 0 2 32 64 8 111 48 39; do
                   C2M_SPLIT_ABL=$abl timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace -f csv -d $O/abl_$abl -o c -- python $R/scripts/bench_conv.py --algo split16 --only 'body 64->64 @640' --iters 6 > $O/abl_$abl.log 2>&1
