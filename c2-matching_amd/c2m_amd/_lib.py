@@ -30,7 +30,7 @@ class Conv3x3Desc(ctypes.Structure):
                 ("res2", _vp), ("mask_out", _vp), ("flow", _vp), ("fh", _i), ("fw", _i), ("scale", _i), ("n_off", _i),
                 ("abs_sum", _vp), ("algo", _i), ("cout_offset", _i), ("cout_total", _i),
                 ("out2", _vp), ("out2_row_pitch", _i), ("out2_plane_pitch", ctypes.c_longlong),
-                ("out2_img_pitch", ctypes.c_longlong), ("range_flag", _vp)]
+                ("out2_img_pitch", ctypes.c_longlong), ("range_flag", _vp), ("io_flags", ctypes.c_int)]
 
 
 class C2MError(RuntimeError):

@@ -447,18 +447,19 @@ class _WeightCache:
 _wcache = _WeightCache()
 
 
-def _nhwc_src(t, name):
-    """channels_last float32 GPU tensor (logical [B,C,H,W], channel stride 1) or a channel slice of one -> ConvSrc."""
-    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
-        raise _lib.C2MError(f"{name} must be a 4-D float32 GPU tensor")
+def _nhwc_src(t, name, bf16_ok=False):
+    """channels_last float32 GPU tensor (logical [B,C,H,W], channel stride 1) or a channel slice of one -> ConvSrc.
+    bf16_ok: bfloat16 tensors pass too (pitches are in elements either way; c2m_conv3x3_desc.io_flags names the types)."""
+    if not t.is_cuda or t.dim() != 4 or not (t.dtype == torch.float32 or (bf16_ok and t.dtype == torch.bfloat16)):
+        raise _lib.C2MError(f"{name} must be a 4-D float32 GPU tensor" + (" (or bfloat16)" if bf16_ok else ""))
     sb, sc, sh, sw = t.stride()
     if sc != 1:
         raise _lib.C2MError(f"{name} must be channels-last (stride 1 along C); got strides {t.stride()}")
     return _lib.ConvSrc(t.data_ptr(), t.shape[1], sw, sh, sb)
 
 
-def empty_nhwc(B, C, H, W, device):
-    return torch.empty((B, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+def empty_nhwc(B, C, H, W, device, dtype=torch.float32):
+    return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=torch.channels_last)
 
 
 import os as _os
@@ -590,8 +591,12 @@ def _split_ok(srcs, weight, fast):
 
 
 def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,
-            out2_grouped8=None, fast=False):
+            out2_grouped8=None, fast=False, out_dtype=None):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
+
+    bf16 tensors ("bf16" kernel and "nhwc" mode only -- what a bf16-autocast forward keeps its activations in between fused
+    convolutions, BASELINE configs[4]): a single bfloat16 source, bfloat16 residuals and `out_dtype=torch.bfloat16` (or a
+    bfloat16 `out`) are accepted in any combination with float32 ones; sums stay fp32, one rounding at the store.
 
     srcs: one or two channels_last tensors [B,Ci,H,W] (each Ci % 32 == 0; a single source with fewer input channels than
     the (zero-padded) weight is not accepted -- pad the tensor).  out_mode: "nhwc" -> channels_last [B,Cout,H,W];
@@ -632,7 +637,22 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     for k, s in enumerate(srcs):
         if tuple(s.shape[2:]) != (H, W) or s.shape[0] != B:
             raise _lib.C2MError("conv3x3: sources must share B, H, W")
-        d.src[k] = _nhwc_src(s, f"src{k}")
+        d.src[k] = _nhwc_src(s, f"src{k}", bf16_ok=True)
+    io = 1 if srcs[0].dtype == torch.bfloat16 else 0
+    if any(s.dtype == torch.bfloat16 for s in srcs[1:]) or (io and len(srcs) != 1):
+        raise _lib.C2MError("conv3x3: a bfloat16 source must be the only source")
+    if out is not None:
+        out_dtype = out.dtype
+    if out_dtype == torch.bfloat16:
+        io |= 2
+    elif out_dtype not in (None, torch.float32):
+        raise _lib.C2MError("conv3x3: out_dtype is float32 or bfloat16")
+    for bit, r in ((4, res1), (8, res2)):
+        if r is not None and r.dtype == torch.bfloat16:
+            io |= bit
+    if io and (wino != 4 or out_mode != "nhwc"):
+        raise _lib.C2MError("conv3x3: bfloat16 tensors need the bf16 kernel (algo='bf16' / bf16 autocast) in nhwc mode")
+    d.io_flags = io
     d.wr = wr.data_ptr()
     if bias is not None:
         bias = _dev_f32(bias.detach(), "bias")
@@ -640,13 +660,13 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     d.act, d.slope = int(act), float(slope)
     if out_mode == "nhwc":
         if out is None:
-            out = empty_nhwc(B, Cout, H, W, dev)
+            out = empty_nhwc(B, Cout, H, W, dev, torch.bfloat16 if io & 2 else torch.float32)
         d.out_mode = 0
-        o = _nhwc_src(out, "out")
+        o = _nhwc_src(out, "out", bf16_ok=True)
         d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = o.pix_pitch, o.row_pitch, o.img_pitch
         for name, r in (("res1", res1), ("res2", res2)):
             if r is not None:
-                rs = _nhwc_src(r, name)
+                rs = _nhwc_src(r, name, bf16_ok=True)
                 if (rs.pix_pitch, rs.row_pitch, rs.img_pitch) != (o.pix_pitch, o.row_pitch, o.img_pitch) or r.shape != out.shape:
                     raise _lib.C2MError(f"{name} must have the geometry of the output")
                 setattr(d, name, r.data_ptr())

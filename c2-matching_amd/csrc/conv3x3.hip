@@ -1562,6 +1562,14 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.out2 = d->out2; p.out2_row_pitch = d->out2_row_pitch; p.out2_plane_pitch = d->out2_plane_pitch;
   p.out2_img_pitch = d->out2_img_pitch;
   p.range_flag = d->range_flag;
+  p.io_flags = d->io_flags;
+  if (d->io_flags != 0) {
+    if (d->algo != C2M_CONV_BF16 || d->out_mode != 0 || (d->io_flags & ~15)) return C2M_ERR_UNSUPPORTED;
+    if ((d->io_flags & C2M_IO_SRC_BF16) && (d->nsrc != 1 || d->src[0].pix_pitch % 8 != 0 || d->src[0].row_pitch % 8 != 0 || d->src[0].img_pitch % 8 != 0))
+      return C2M_ERR_UNSUPPORTED;   // 16-byte pieces of 8 bf16
+    if (d->Cout % ((d->io_flags & C2M_IO_OUT_BF16) ? 8 : 4) != 0) return C2M_ERR_UNSUPPORTED;   // 16-byte stores
+    if ((d->io_flags & C2M_IO_OUT_BF16) && (d->out_pix_pitch % 8 != 0 || d->out_row_pitch % 8 != 0 || d->out_img_pitch % 8 != 0)) return C2M_ERR_UNSUPPORTED;
+  }
   if (d->out2 && (wino || d->out_mode != 0 || !out_vec4 || d->Cout % 8 != 0 || ((uintptr_t)d->out2 & 15) ||
                   d->out2_row_pitch % 4 != 0 || d->out2_plane_pitch % 4 != 0 || d->out2_img_pitch % 4 != 0))
     return C2M_ERR_UNSUPPORTED;

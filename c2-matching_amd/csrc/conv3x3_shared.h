@@ -40,6 +40,7 @@ struct Params {
   float* out2;           // mode 0 (direct kernel, float4 stores): second copy of the output, 8-channel group-major
   int out2_row_pitch;    //   out2[b*img + (co/8)*plane + y*row + x*8 + co%8]: the layout the DCNv2 kernel gathers 8-channel
   long long out2_plane_pitch, out2_img_pitch;   // groups from (c2m_dcn_v2_forward_nhwc_f32, input_grouped)
+  int io_flags;          // bf16 flavour: C2M_IO_* (element types of src[0] / out / res1 / res2)
   int* range_flag;       // f16 x 2 flavour: set to 1 if an input activation lies outside the flavour's domain (|x| >= 65520)
 };
 

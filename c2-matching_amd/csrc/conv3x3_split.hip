@@ -272,17 +272,23 @@ __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
 // ABL > 0: timing-only ablations (WRONG results; $C2M_SPLIT_ABL), a bit mask: 1 no weight DMA after the prologue, 2 no halo
 // DMA, 4 no split of the raw tile (only together with 2: loads into dead registers are unsafe), 8 no unit-end waits /
 // barriers, 16 no MFMAs, 32 no operand reads
-template <int FL, int MT, int MODE, int ABL = 0>
+// IO16 (bf16 flavour, channels-last mode, one source): the source tensor holds bf16 -- 16 channels of a pixel are two 16-byte
+// pieces that ARE plane entries, so the halo tile goes HBM -> LDS by LDS-DMA (no registers, no split rounds, 3 pieces per wave
+// and chunk instead of 6 register loads; zero fill outside the image by the buffer's range check), two chunks ahead into a
+// ring of THREE plane buffers.  Output / residual element types follow Params::io_flags (any FL = 1 launch).
+template <int FL, int MT, int MODE, int ABL = 0, bool IO16 = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
+  static_assert(!IO16 || (FL == 1 && MODE == 0 && ABL == 0), "bf16 sources: the bf16 flavour's channels-last mode");
   constexpr int NT = 2;
   constexpr int MW = 32 * MT;
   using PR = Flavour<FL>;
   constexpr int NPX = PR::NPX, NPW = PR::NPW;
-  constexpr int PLB = NPX * 2 * HALFB;          // bytes of one plane buffer
+  // bytes of one plane buffer (IO16: 12 whole wave-pieces of 1 KiB -- the 24 slots behind the 680 pieces of a chunk take zeros)
+  constexpr int PLB = IO16 ? 12 * 1024 : NPX * 2 * HALFB;
   // PIPE: two plane buffers -- the split of chunk c+1 is interleaved with the MFMAs of chunk c (no phase (A), no barrier for
   // it).  The bf16 x 3 flavour keeps one buffer and phase (A): two of its workgroups would not fit a CU otherwise.
   constexpr bool PIPE = FL != 3;
-  constexpr int NPB = PIPE ? 2 : 1;
+  constexpr int NPB = IO16 ? 3 : (PIPE ? 2 : 1);
   constexpr int NRING = PIPE ? 3 : 2;           // weight ring slots; unit u's weights are issued NRING-1 units ahead
   constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
   constexpr int WUNIT = 3 * WTAP;               // unit = one kernel row
@@ -349,6 +355,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     const int ry = pix / HWc, rx = pix - ry * HWc;
     slotc[sl] = ry | (rx << 8) | ((l & 3) << 16) | (pix < NPIX ? (1 << 24) : 0);
   }
+  // IO16: piece pid = 64 (wv + 4 sl) + l = (k half pid / 340, halo pixel pid % 340) -> LDS byte pid * 16 of the plane buffer
+  unsigned dvoff[3] = {kOOB, kOOB, kOOB};
+  __amdgpu_buffer_rsrc_t in_rs16 = make_rsrc(p.src[0].ptr, 0u);
+  auto set_source16 = [&](const Src& S) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      const int pid = 64 * (wv + 4 * sl) + l, kh = pid >= NPIX ? 1 : 0, pix = pid - kh * NPIX;
+      const int ry = pix / HWc, rx = pix - ry * HWc;
+      const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
+      const bool ok = pid < 2 * NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      dvoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 8 * kh) * 2u : kOOB;
+    }
+  };
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
 #pragma unroll
     for (int sl = 0; sl < NRAW_W; ++sl) {
@@ -368,6 +387,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     const int c0 = dma_c * KC;
     in_first = c0 < p.src[0].C;
     if (++dma_c == p.nchunks) dma_c = 0;
+    if constexpr (IO16) {
+      if (c0 == 0) {
+        ib = dma_tc.b; iy0 = dma_tc.ty * THY; ix0 = dma_tc.tx * TWX;
+        tc_next(dma_tc);
+        const Src& S = p.src[0];   // (pitches of a bf16 source are in bf16 elements)
+        in_rs16 = make_rsrc(reinterpret_cast<const char*>(S.ptr) + (long long)ib * S.img_pitch * 2,
+                            (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 2u);
+        set_source16(S);
+      }
+      in_soff = c0 * 2;
+      return;
+    }
     if (c0 == 0) {
       ib = dma_tc.b; iy0 = dma_tc.ty * THY; ix0 = dma_tc.tx * TWX;
       tc_next(dma_tc);
@@ -378,6 +409,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       set_source(p.src[1]);
     }
     in_soff = (in_first ? c0 : c0 - p.src[0].C) * 4;
+  };
+  // IO16: piece `sl` of the chunk issue_in_begin() has just set up -> plane buffer at byte offset `plane_off`
+  auto issue_in_dma = [&](int sl, unsigned plane_off) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs16, (__attribute__((address_space(3))) void*)(pl_base + plane_off + (unsigned)(wv + 4 * sl) * 1024u), 16,
+                                             dvoff[sl], in_soff, 0, 0);
   };
   f32x4 rawr[NRAW_W];
   auto issue_in_piece = [&](auto slc) __attribute__((always_inline)) {
@@ -455,7 +491,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // prologue: the raw pieces of chunk 0 and the weights of unit 0
   // ------------------------------------------------------------------------------------------------------------------
   issue_in_begin();
-  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
+  if constexpr (IO16) {
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) issue_in_dma(sl, 0u);
+  } else {
+    static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
+  }
 #pragma unroll
   for (int i = 0; i < NW_W; ++i) issue_w_piece(0u, i);
   issue_w_done();
@@ -466,8 +507,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       issue_w_done();
     }
   }
+  if constexpr (IO16) {   // chunk 1 -> plane buffer 1; both landed and published before the first unit
+    if (G > 1) {
+      issue_in_begin();
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) issue_in_dma(sl, (unsigned)PLB);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   wait_vmcnt<0>();
-  if constexpr (PIPE) {   // chunk 0 -> plane buffer 0; the registers re-load with chunk 1
+  if constexpr (PIPE && !IO16) {   // chunk 0 -> plane buffer 0; the registers re-load with chunk 1
     const bool more1 = !(ABL & 2) && G > 1;
     if (more1) issue_in_begin();
     static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
@@ -502,7 +553,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       // PIPE: the registers hold chunk gc+1 (if any); they re-load with chunk gc+2.  Else: they hold chunk gc, re-load with gc+1
       const bool has_next = PIPE ? gc + 1 < G : true;
       const bool more_in = !(ABL & 2) && gc + (PIPE ? 2 : 1) < G;
-      const unsigned pb = PIPE ? (unsigned)(gc & 1) * PLB : 0u;
+      const unsigned pb = IO16 ? (unsigned)(gc % 3) * PLB : PIPE ? (unsigned)(gc & 1) * PLB : 0u;
+      const unsigned pb_in = (unsigned)((gc + 2) % 3) * PLB;   // IO16: where chunk gc+2 lands
       const unsigned bcur = bbase + pb, cnext = PIPE ? cdst + (PLB - pb) : cdst;
       if (more_in) issue_in_begin();
       if constexpr (!PIPE) {
@@ -570,7 +622,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                 Ad[mt] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, A[set][0][mt]) * sc);
               }
             }
-            if constexpr (PIPE && dx >= 1 && g == NG / 2 && !(ABL & 4)) {   // split round R of the next chunk
+            if constexpr (IO16 && dx == 1 && g == NG / 2) {   // halo piece dy of chunk gc+2 (one per unit)
+              if (more_in) issue_in_dma(dy, pb_in);
+            }
+            if constexpr (PIPE && !IO16 && dx >= 1 && g == NG / 2 && !(ABL & 4)) {   // split round R of the next chunk
               constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
               if (has_next) {
                 if constexpr (dy == 0) {
@@ -605,7 +660,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           // PIPE, steady state: the weights of unit u+1 (issued in unit u-1) landed, and with them every raw load older than
           // unit u-1's; still in flight may be: raw(u-1) x 2, W(u+2) x NW_W, raw(u) x 2.  (vmcnt counts in issue order.)
-          if (PIPE && more_in) {
+          if (IO16 && more_in) {
+            wait_vmcnt<2 + NW_W>();   // in flight may be: halo piece of unit u-1, W(u+2) x NW_W, halo piece of unit u
+          } else if (PIPE && !IO16 && more_in) {
             if ((ABL & 128) && c == 0 && dy == 0) wait_vmcnt<4 + NW_W + 16>();
             else wait_vmcnt<4 + NW_W>();
           } else wait_vmcnt<0>();
@@ -717,6 +774,50 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
             float* ob = p.out + opix + co_lane;
+            if constexpr (FL == 1) {
+              if (p.io_flags & 2) {
+                // bf16 output (Cout % 8 == 0): lanes j and j + 32 hold channels 8qd + 0..3 / 8qd + 4..7 of the same pixel;
+                // v_permlane32_swap hands lane j the whole 8-channel group 2k and lane j + 32 the whole group 2k + 1, so
+                // that a lane stores (and fetches its residuals as) 16 bytes: 8 stores per wave and tile instead of 16
+                typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                  for (int k = 0; k < 2; ++k) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      // (copies first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc)
+                      const float lo = acc[mt][nt][8 * k + e], up = acc[mt][nt][8 * k + 4 + e];
+                      const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, up), false, false);
+                      const unsigned r0 = r[0], r1 = r[1];
+                      v[e] = __builtin_bit_cast(float, r0);
+                      v[4 + e] = __builtin_bit_cast(float, r1);
+                    }
+                    const int co8 = cb * MW + mt * 32 + 8 * (2 * k + hi);
+                    if (co8 + 7 < p.Cout) {
+                      auto res = [&](const float* r, bool is16) __attribute__((always_inline)) {
+                        if (is16) {
+                          const bf16x8v h = *reinterpret_cast<const bf16x8v*>(reinterpret_cast<const __bf16*>(r) + opix + co8);
+#pragma unroll
+                          for (int e = 0; e < 8; ++e) v[e] += (float)h[e];
+                        } else {
+                          const f32x4 a = *reinterpret_cast<const f32x4*>(r + opix + co8), c = *reinterpret_cast<const f32x4*>(r + opix + co8 + 4);
+#pragma unroll
+                          for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += c[e]; }
+                        }
+                      };
+                      if (p.res1) res(p.res1, (p.io_flags & 4) != 0);
+                      if (p.res2) res(p.res2, (p.io_flags & 8) != 0);
+                      bf16x8v h;
+#pragma unroll
+                      for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+                      *reinterpret_cast<bf16x8v*>(reinterpret_cast<__bf16*>(p.out) + opix + co8) = h;
+                    }
+                  }
+                continue;
+              }
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -725,6 +826,28 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+                if constexpr (FL == 1) {
+                  // bf16 flavour: the output / the residuals may hold bf16 (Params::io_flags; Cout % 4 == 0 then) -- the sum
+                  // is taken in fp32 and rounded once
+                  if (p.io_flags & 12) {   // fp32 output, bf16 residual(s)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    if (co + 3 < p.Cout) {
+                      auto res = [&](const float* r, bool is16) __attribute__((always_inline)) {
+                        if (is16) {
+                          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(r) + opix + co);
+#pragma unroll
+                          for (int e = 0; e < 4; ++e) v[e] += (float)h[e];
+                        } else {
+                          v += *reinterpret_cast<const f32x4*>(r + opix + co);
+                        }
+                      };
+                      if (p.res1) res(p.res1, (p.io_flags & 4) != 0);
+                      if (p.res2) res(p.res2, (p.io_flags & 8) != 0);
+                      *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+                    }
+                    continue;
+                  }
+                }
                 if (co + 3 < p.Cout) {
                   // (residuals are fetched here: the co-resident workgroup's MFMAs cover the latency)
                   if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + opix + co);
@@ -834,6 +957,16 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ldsb, dn)) == C2M_OK)
       hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
   };
+  if constexpr (NP == 1) {
+    if (p.io_flags & C2M_IO_SRC_BF16) {   // bf16 source: three 12 KiB plane buffers filled by LDS-DMA
+      constexpr size_t lds16 = (size_t)3 * 12 * 1024 + 3 * (size_t)(3 * MT * 1024) + 1024 + 256;
+      static unsigned long long done16 = 0;
+      auto kern = &split::conv3x3_split_kernel<1, MT, 0, 0, true>;
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds16, done16)) == C2M_OK)
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds16, st, p);
+      return rc;
+    }
+  }
   if constexpr (NP == 2 && MT == 2) {   // (timing-only ablations exist for the f16 x 2 flavour on 64-wide cout tiles)
     static const int abl = [] {
       const char* e = getenv("C2M_SPLIT_ABL");

@@ -103,10 +103,29 @@ def _fused_body(body, f, skip=None):
     ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue.  fast=True: decoder
     convolutions may take the Winograd F(4,3) kernel (ops.conv3x3) where the map is a whole number of 64-pixel tiles wide."""
     n = len(body)
+    if _BF16_IO and _ops.bf16_autocast() and blk_bf16_ok(body):
+        # bf16 autocast (BASELINE configs[4]): the residual stream and the block-internal tensor travel as bf16 -- half the
+        # HBM bytes of these launches, the tile goes HBM -> LDS without passing registers (c2m_conv3x3_desc.io_flags).  Sums
+        # (bias, residuals) are taken in fp32 inside the kernel; the body's result leaves as fp32.  (torch's own autocast
+        # keeps every conv output in bf16 as well: arch_util.py:128-136 under autocast.)
+        bf = torch.bfloat16
+        for k, blk in enumerate(body):
+            t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU, fast=True, out_dtype=bf)
+            f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None, fast=True,
+                             out_dtype=None if k == n - 1 else bf)
+        return f
     for k, blk in enumerate(body):
         t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU, fast=True)
         f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None, fast=True)
     return f
+
+
+# $C2M_BF16_IO=0: under bf16 autocast keep fp32 tensors between the fused convolutions (the round-3 behaviour)
+_BF16_IO = _os.environ.get("C2M_BF16_IO", "1") != "0"
+
+
+def blk_bf16_ok(body):
+    return all(b.conv1.weight.shape[0] % 16 == 0 and b.conv1.weight.shape[1] % 16 == 0 and b.conv2.weight.shape[0] % 16 == 0 for b in body)
 
 
 class DynamicAggregationRestoration(nn.Module):

@@ -281,7 +281,17 @@ typedef struct c2m_conv3x3_desc {
                               results are to be recomputed with C2M_CONV_SPLIT_BF16X3 (what c2m_amd.ops.f16_range_guard and
                               the fused module forwards do, so that a drop-in never returns NaN where nn.Conv2d returns a
                               number: arch_util.py:80-136) */
+  int io_flags;            /* C2M_CONV_BF16 + C2M_OUT_NHWC only, else 0: element types of the tensors of a bf16 (autocast)
+                              forward, so that activations travel between the fused convolutions as bf16 (half the HBM bytes;
+                              BASELINE configs[4]).  Bit 0: src[0] holds bf16 (nsrc = 1; pitches in ELEMENTS, multiples of 8,
+                              the tile goes HBM -> LDS by DMA without passing registers); bit 1: `out` holds bf16; bit 2 / 3:
+                              res1 / res2 hold bf16.  Pointers are passed as float* regardless.  Accumulation, bias,
+                              activation and the residual adds stay fp32; one rounding at the store */
 } c2m_conv3x3_desc;
+#define C2M_IO_SRC_BF16 1
+#define C2M_IO_OUT_BF16 2
+#define C2M_IO_RES1_BF16 4
+#define C2M_IO_RES2_BF16 8
 
 size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */
 int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight /* [Cout][Cin][3][3] */, int Cin, int Cout, float* wr);

@@ -30,6 +30,8 @@ for stage in "$@"; do
                 timeout 300 python bench.py --lr 320 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_f32.log 2>&1 ;;
     bench_cfg5_bf16) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16.log 2>&1
                 C2M_BF16_IO=0 timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16_f32io.log 2>&1 ;;
+    dbg_bf16)   timeout 300 python scripts/debug/bf16io.py > $O/dbg_bf16.log 2>&1
+                timeout 600 python -m pytest tests/test_restoration_gpu.py -m gpu -q -x -k "full_chain_under_bf16" 2>&1 | tail -60 >> $O/dbg_bf16.log ;;
     test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;

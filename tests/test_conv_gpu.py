@@ -427,6 +427,69 @@ def test_conv3x3_bf16_single_piece_is_a_bf16_convolution(ops, dev):
     assert 1e-4 < rel < 1e-2, rel
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 20, 48), (1, 64, 37, 70), (3, 32, 8, 32), (1, 128, 19, 33), (1, 64, 64, 256)])
+def test_conv3x3_bf16_tensors_in_and_out(ops, dev, shape):
+    """c2m_conv3x3_desc.io_flags: bf16 source (tile by LDS-DMA into three plane buffers), bf16 output (lane-swapped 16-byte
+    stores), bf16 / fp32 residuals in every combination -- against a float64 convolution of the SAME bf16-rounded operands:
+    fp32 outputs to fp32 summation error, bf16 outputs to one bf16 rounding (2^-9 relative) of the fp32 result."""
+    B, C, H, W = shape
+    bf = torch.bfloat16
+    x = _cl(_rand((B, C, H, W), dev, 330))
+    w, b = _rand((C, C, 3, 3), dev, 331, 1.0 / 24.0), _rand((C,), dev, 332)
+    r1, r2 = _cl(_rand((B, C, H, W), dev, 333)), _cl(_rand((B, C, H, W), dev, 334))
+    xh = x.to(bf).contiguous(memory_format=torch.channels_last)
+    r1h = r1.to(bf).contiguous(memory_format=torch.channels_last)
+    wb = w.bfloat16().double()
+    core = F.conv2d(xh.double(), wb, b.double(), padding=1)
+    cases = [  # (source, act, res1, res2, out dtype)
+        (xh, ops.ACT_RELU, None, None, None),
+        (xh, ops.ACT_NONE, r1h, None, bf),
+        (xh, ops.ACT_NONE, r1h, r2, None),
+        (xh, ops.ACT_LRELU, r1, r2, bf),
+        (x, ops.ACT_RELU, None, None, bf),
+        (x, ops.ACT_NONE, r1h, None, None),
+    ]
+    for src, act, a1, a2, od in cases:
+        got = ops.conv3x3(src, w, b, act=act, slope=0.1, res1=a1, res2=a2, algo="bf16", out_dtype=od)
+        assert got.dtype == (od or torch.float32) and got.is_contiguous(memory_format=torch.channels_last)
+        want = core if src is xh else F.conv2d(x.bfloat16().double(), wb, b.double(), padding=1)
+        want = want.relu() if act == ops.ACT_RELU else F.leaky_relu(want, 0.1) if act == ops.ACT_LRELU else want
+        for r in (a1, a2):
+            if r is not None:
+                want = want + r.double()
+        scale = float(want.abs().max())
+        err = (got.double() - want).abs()
+        if od is None:
+            assert float(err.max()) < 1e-5 * scale, (src.dtype, act, od)
+        else:
+            assert bool((err <= want.abs() * 2.0 ** -8 + 1e-5 * scale).all()), (src.dtype, act, od, float(err.max()))
+            again = ops.conv3x3(src, w, b, act=act, slope=0.1, res1=a1, res2=a2, algo="bf16")   # fp32 out, rounded here
+            assert torch.equal(again.to(bf), got)
+
+
+def test_conv3x3_bf16_tensors_views_and_rejections(ops, dev):
+    """bf16 tensors as channel slices / row-pitched views; what the boundary refuses (two sources, other kernels, other modes)."""
+    bf = torch.bfloat16
+    big = _cl(_rand((2, 128, 24, 40), dev, 340)).to(bf).contiguous(memory_format=torch.channels_last)
+    xs = big[:, 32:96]
+    w, b = _rand((64, 64, 3, 3), dev, 341, 0.05), _rand((64,), dev, 342)
+    outbig = torch.zeros((2, 128, 24, 40), dtype=bf, device=dev).contiguous(memory_format=torch.channels_last)
+    ops.conv3x3(xs, w, b, out=outbig[:, 64:], algo="bf16")
+    want = F.conv2d(xs.double(), w.bfloat16().double(), b.double(), padding=1)
+    err = (outbig[:, 64:].double() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -8 + 1e-5 * float(want.abs().max())).all())
+    assert float(outbig[:, :64].abs().max()) == 0
+    from c2m_amd._lib import C2MError
+    with pytest.raises(C2MError):
+        ops.conv3x3([xs, xs], _rand((64, 128, 3, 3), dev, 343), None, algo="bf16")
+    with pytest.raises(C2MError):
+        ops.conv3x3(xs, w, b, algo="split")
+    with pytest.raises(C2MError):
+        ops.conv3x3(xs, w, b, algo="bf16", out_mode="nchw")
+    with pytest.raises(C2MError):
+        ops.conv3x3(xs.float(), w, b, algo="split16", out_dtype=bf)
+
+
 @pytest.mark.parametrize("algo", SPLIT_ALGOS)
 def test_dcn_head_on_the_split_kernel(ops, dev, algo):
     """DCN offset/mask head epilogue of the split kernel (192 + 24 channels): same check as the fp32-MFMA kernels'."""
