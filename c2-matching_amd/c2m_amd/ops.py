@@ -145,6 +145,22 @@ class corr_filter_mode:
         return False
 
 
+class head_store_mode:
+    """`with ops.head_store_mode(0): ...` -- the DCN head epilogue's dword planar stores; (1): 16-byte stores through the quad
+    transpose + flow window (default where W % 4 == 0); identical results (c2m_conv3x3_set_head_stores).  Process-wide."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        _lib.check(_lib.lib().c2m_conv3x3_set_head_stores(self.mode), "c2m_conv3x3_set_head_stores")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.lib().c2m_conv3x3_set_head_stores(-1), "c2m_conv3x3_set_head_stores")
+        return False
+
+
 def last_corr_skip_table():
     """Duplicate-row table recorded under `record_corr_skip_table()`: int32 [B, x_tiles, 2] = (from, to), ref rows
     [from, to) of that (sample, x-tile) were not swept (c2m_feature_match_skip_table).  Diagnostics / bench only."""

@@ -1394,6 +1394,7 @@ namespace conv {   // conv3x3_split.hip
 size_t split_relayout_bytes(int Cin, int Cout, int np);
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad);
 int launch_split(hipStream_t st, Params p, int np);
+int set_head_stores(int mode);
 int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long long nblocks, int any_f16);
 }  // namespace conv
 }  // namespace c2m
@@ -1499,6 +1500,8 @@ extern "C" int c2m_index_to_flow_f32(c2m_stream_t stream, const int64_t* max_idx
                      wq, reinterpret_cast<float2*>(flow));
   return check_launch();
 }
+
+extern "C" int c2m_conv3x3_set_head_stores(int mode) { return conv::set_head_stores(mode); }
 
 extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc* d) {
   if (!d || !d->wr || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->nsrc < 1 ||

@@ -278,7 +278,7 @@ __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
 // ring of THREE plane buffers.  Output / residual element types follow Params::io_flags (any FL = 1 launch).
 template <int FL, int MT, int MODE, int ABL = 0, bool IO16 = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
-  static_assert(!IO16 || (FL == 1 && MODE == 0 && ABL == 0), "bf16 sources: the bf16 flavour's channels-last mode");
+  static_assert(!IO16 || (FL == 1 && MODE == 0 && (ABL & 4) == 0), "bf16 sources: the bf16 flavour's channels-last mode");
   constexpr int NT = 2;
   constexpr int MW = 32 * MT;
   using PR = Flavour<FL>;
@@ -699,25 +699,37 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r & 3] += acc[mt][nt][r];
       const int y = y0 + 2 * wv, x = x0 + j;
-      if (y < p.H && x < p.W)
-        *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co_lane) = v;
-    } else if constexpr (MODE == 3) {
+      if (y < p.H && x < p.W) {
+        const size_t o = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co_lane;
+        if constexpr (IO16) *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(p.out) + 2 * (o / 2)) = v;   // (stays inside a bf16 tensor)
+        else *reinterpret_cast<f32x4*>(p.out + o) = v;
+      }
+    } else if constexpr (MODE == 3 || MODE == 5) {
       float asum = 0.0f;
       const HeadOut ho = head_out(p, b);
+      // MODE 5 (W % 4 == 0; $C2M_HEAD_QUAD=0 keeps MODE 3): 16-byte planar stores after a 4 x 4 transpose inside the lane
+      // quads, pre-offsets from a per-row flow window held in registers (conv3x3_shared.h)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int y = y0 + 2 * wv + nt, x = x0 + j;
         const bool pok = y < p.H && x < p.W;
+        HeadFlowWin fwin;
+        if constexpr (MODE == 5) fwin = head_flow_window(p, b, min(y, p.H - 1), x0, l);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             const int col = co_lane + mt * 32 + 8 * qd;   // channel inside this launch's slice
-            if (col >= p.Cout || !pok) continue;
+            if constexpr (MODE == 5) {
+              if (col - 4 * hi >= p.Cout) continue;       // (wave-uniform: the whole 8-channel group lies beyond the slice)
+            } else {
+              if (col >= p.Cout || !pok) continue;
+            }
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
-            asum += dcn_head_store(p, ho, b, y, x, col - 4 * hi, 4 * hi, v);
+            if constexpr (MODE == 5) asum += dcn_head_store_quad(p, ho, y, x, col - 4 * hi, 4 * hi, v, j, fwin, pok && col + 3 < p.Cout);
+            else asum += dcn_head_store(p, ho, b, y, x, col - 4 * hi, 4 * hi, v);
           }
       }
       // (Round 4 staged this epilogue -- and the planar NCHW one -- through a per-wave [32 channels][32 pixels] LDS tile so that
@@ -947,6 +959,8 @@ int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long 
   return check_launch();
 }
 
+int g_head_stores = -1;   // c2m_conv3x3_set_head_stores
+
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
   constexpr size_t ldsb = (size_t)((NP != 3 ? 2 : 1) * split::npx_of(NP) * 2 * split::HALFB) + (NP != 3 ? 3 : 2) * (size_t)(3 * split::npw_of(NP) * MT * 1024) + 1024 +
@@ -961,9 +975,33 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
     if (p.io_flags & C2M_IO_SRC_BF16) {   // bf16 source: three 12 KiB plane buffers filled by LDS-DMA
       constexpr size_t lds16 = (size_t)3 * 12 * 1024 + 3 * (size_t)(3 * MT * 1024) + 1024 + 256;
       static unsigned long long done16 = 0;
-      auto kern = &split::conv3x3_split_kernel<1, MT, 0, 0, true>;
-      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds16, done16)) == C2M_OK)
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds16, st, p);
+      auto go16 = [&](auto kern, unsigned long long& dn) {
+        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds16, dn)) == C2M_OK)
+          hipLaunchKernelGGL(kern, grid, dim3(256), lds16, st, p);
+      };
+      if constexpr (MT == 2) {   // (timing-only ablations, as for the f16 x 2 flavour: $C2M_SPLIT_ABL16)
+        static const int abl = [] {
+          const char* e = getenv("C2M_SPLIT_ABL16");
+          const int v = e ? atoi(e) : 0;
+          if (v > 0) fprintf(stderr, "c2m: C2M_SPLIT_ABL16=%d -- the bf16-tensor conv3x3 kernel runs a timing-only ablation, its results are wrong\n", v);
+          return v;
+        }();
+        static unsigned long long dn[9] = {};
+        switch (abl) {
+          case 0: break;
+          case 1: go16(&split::conv3x3_split_kernel<1, 2, 0, 1, true>, dn[0]); return rc;
+          case 2: go16(&split::conv3x3_split_kernel<1, 2, 0, 2, true>, dn[1]); return rc;
+          case 8: go16(&split::conv3x3_split_kernel<1, 2, 0, 8, true>, dn[2]); return rc;
+          case 16: go16(&split::conv3x3_split_kernel<1, 2, 0, 16, true>, dn[3]); return rc;
+          case 32: go16(&split::conv3x3_split_kernel<1, 2, 0, 32, true>, dn[4]); return rc;
+          case 64: go16(&split::conv3x3_split_kernel<1, 2, 0, 64, true>, dn[5]); return rc;
+          case 43: go16(&split::conv3x3_split_kernel<1, 2, 0, 43, true>, dn[6]); return rc;
+          case 48: go16(&split::conv3x3_split_kernel<1, 2, 0, 48, true>, dn[7]); return rc;
+          case 107: go16(&split::conv3x3_split_kernel<1, 2, 0, 107, true>, dn[8]); return rc;
+          default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL16 mask\n"); return C2M_ERR_INVALID_ARG;
+        }
+      }
+      go16(&split::conv3x3_split_kernel<1, MT, 0, 0, true>, done16);
       return rc;
     }
   }
@@ -999,7 +1037,14 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
     case 0: go(&split::conv3x3_split_kernel<NP, MT, 0>, done[0]); break;
     case 1: go(&split::conv3x3_split_kernel<NP, MT, 1>, done[1]); break;
     case 2: go(&split::conv3x3_split_kernel<NP, MT, 2>, done[2]); break;
-    case 3: go(&split::conv3x3_split_kernel<NP, MT, 3>, done[3]); break;
+    case 3: {
+      static const int env_quad = [] { const char* e = getenv("C2M_HEAD_QUAD"); return e ? atoi(e) : 1; }();
+      const int head_quad = g_head_stores >= 0 ? g_head_stores : env_quad;
+      static unsigned long long done5 = 0;
+      if (head_quad != 0 && p.W % 4 == 0) go(&split::conv3x3_split_kernel<NP, MT, 5>, done5);
+      else go(&split::conv3x3_split_kernel<NP, MT, 3>, done[3]);
+      break;
+    }
     default: go(&split::conv3x3_split_kernel<NP, MT, 4>, done[4]); break;
   }
   return rc;
@@ -1031,6 +1076,12 @@ int launch_split(hipStream_t st, Params p, int np) {
   else rc = MT == 2 ? launch_split_mode<1, 2>(st, p, grid) : launch_split_mode<1, 1>(st, p, grid);
   if (rc != C2M_OK) return rc;
   return check_launch();
+}
+
+int set_head_stores(int mode) {
+  if (mode < -1 || mode > 1) return C2M_ERR_INVALID_ARG;
+  g_head_stores = mode;
+  return C2M_OK;
 }
 
 }  // namespace conv

@@ -97,6 +97,15 @@ int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* 
 int c2m_feature_match_set_filter(int mode);
 
 /*
+ * The DCN offset/mask head epilogue (C2M_OUT_DCN_HEAD) of the split kernels has two store paths with identical results:
+ *   1 (default, maps with W % 4 == 0)  16-byte planar stores after a 4 x 4 register transpose inside lane quads, pre-offsets
+ *                                      from a per-row flow window held in registers (ds_bpermute look-ups);
+ *   0                                  dword planar stores, one 8-byte flow load per (4 channels, pixel).
+ * mode: 1 / 0, -1 follow $C2M_HEAD_QUAD (unset = 1).  Process-wide; measurement and tests.
+ */
+int c2m_conv3x3_set_head_stores(int mode);
+
+/*
  * Diagnostics of the pre-filter: after c2m_feature_match_index_f32 took that path the workspace holds int32 [B][Hqp*Wqp]
  * candidate counts at *cnt_offset (-1 = every ref patch was re-scored), int32 [B][Hqp*Wqp][*slots] candidates at
  * *cand_offset (>= 0x40000000: "re-score the whole candidate set of lane (entry & 31)") and int32 flags at *flags_offset

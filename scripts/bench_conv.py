@@ -21,6 +21,7 @@ SHAPES = [  # name, [cin per source], cout, hw, mode
     ("large_offset_conv1 128->64 @640", [64, 64], 64, 640, "nhwc"), ("dcn head 64->216 @640", [64], 216, 640, "head"),
     ("dcn head 256->216 @160", [256], 216, 160, "head"), ("tail_large.0 64->32 @640", [64], 32, 640, "nhwc"),
     ("tail_large.2 32->3 @640", [32], 3, 640, "nchw"),
+    ("body 64->64 @1280", [64], 64, 1280, "nhwc"), ("body+res 64->64 @1280", [64], 64, 1280, "nhwc_res"),
 ]
 
 
@@ -33,12 +34,19 @@ def main():
                                                         "Winograd F(4,3) kernel where the map allows)")
     ap.add_argument("--data", type=str, default="randn", help="randn | zeros | ones (power / clock experiments: the matrix pipe draws less on constant data)")
     ap.add_argument("--algo", type=str, default=None, help="force direct / winograd / winograd4 / split / bf16")
+    ap.add_argument("--io16", action="store_true", help="bf16 tensors in and out (single-source nhwc shapes; implies --algo bf16)")
     args = ap.parse_args()
+    if args.io16:
+        args.algo = "bf16"
     dev = torch.device("cuda:0")
     B = args.batch
     out = []
     for name, cins, co, hw, mode in SHAPES:
         if args.only and args.only not in name:
+            continue
+        if "@1280" in name and (B > 4 or not args.only):
+            continue
+        if args.io16 and (len(cins) != 1 or not mode.startswith("nhwc")):
             continue
         xs = [torch.randn(B, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last) for c in cins]
         w = torch.randn(co, sum(cins), 3, 3, device=dev) * 0.02
@@ -47,14 +55,17 @@ def main():
             fill = 0.0 if args.data == "zeros" else 1.0
             xs = [x.fill_(fill) for x in xs]
             w.fill_(fill * 0.02)
+        if args.io16:
+            xs = [x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for x in xs]
+        od = torch.bfloat16 if args.io16 else None
         flow = torch.zeros(B, hw // (hw // 160) - 2, hw // (hw // 160) - 2, 2, device=dev)
 
         def run():
             if mode == "head":
                 return ops.conv3x3_dcn_head(xs, w, b, 8, flow, hw // 160, algo=args.algo)
             if mode == "nhwc_res":   # second conv of a ResidualBlockNoBN: no activation, + identity
-                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0], fast=args.fast, algo=args.algo)
-            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode, fast=args.fast, algo=args.algo)
+                return ops.conv3x3(xs, w, b, act=ops.ACT_NONE, res1=xs[0], fast=args.fast, algo=args.algo, out_dtype=od)
+            return ops.conv3x3(xs, w, b, act=ops.ACT_RELU, out_mode=mode, fast=args.fast, algo=args.algo, out_dtype=od)
         c2m_amd.profile_enable(True)
         c2m_amd.profile_collect()
         try:

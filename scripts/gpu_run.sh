@@ -32,6 +32,37 @@ for stage in "$@"; do
                 C2M_BF16_IO=0 timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16_f32io.log 2>&1 ;;
     dbg_bf16)   timeout 300 python scripts/debug/bf16io.py > $O/dbg_bf16.log 2>&1
                 timeout 600 python -m pytest tests/test_restoration_gpu.py -m gpu -q -x -k "full_chain_under_bf16" 2>&1 | tail -60 >> $O/dbg_bf16.log ;;
+    prof_cfg5)  cd /tmp
+                timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
+                cd $R
+                python - "$O" <<'PY'
+import csv, sys, glob, collections
+O = sys.argv[1]
+f = glob.glob(O + "/prof_cfg5/**/step_kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0]))) if f else []
+with open(O + "/prof_cfg5_kernel_stats.txt", "w") as out:
+    for r in rows[:40]:
+        out.write("%-110s calls %6s total_ms %9.3f avg_us %9.2f pct %s\n" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+                rm -rf $O/prof_cfg5 ;;
+    bench_conv16) (echo "== bf16 kernel, fp32 tensors, B=4"; timeout 200 python scripts/bench_conv.py --batch 4 --algo bf16 --only body
+                   echo "== bf16 kernel, bf16 tensors, B=4"; timeout 200 python scripts/bench_conv.py --batch 4 --io16 --only body) > $O/bench_conv16.log 2>&1 ;;
+    abl16)      for abl in 0 1 2 8 16 32 64 43 48 107; do
+                  echo "=== C2M_SPLIT_ABL16=$abl (1 no weight DMA, 2 no halo DMA, 8 no waits/barriers, 16 no MFMAs, 32 no operand reads, 64 one store)" >> $O/abl16.txt
+                  C2M_SPLIT_ABL16=$abl timeout 200 python scripts/bench_conv.py --batch 4 --io16 --only '64->64 @1280' --iters 20 2>&1 | grep "^{'layer" >> $O/abl16.txt
+                done ;;
+    abl16_pmc)  cd /tmp
+                for abl in 0 107 16 43; do
+                  C2M_SPLIT_ABL16=$abl timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace -f csv -d $O/abl16_$abl -o c -- python $R/scripts/bench_conv.py --batch 4 --io16 --only 'body 64->64 @1280' --iters 6 > $O/abl16_$abl.log 2>&1
+                  echo "=== C2M_SPLIT_ABL16=$abl" >> $O/abl16_pmc.txt
+                  python $R/scripts/pmc_kernel.py $O/abl16_$abl conv3x3_split_kernel >> $O/abl16_pmc.txt 2>&1
+                  C2M_SPLIT_ABL16=$abl timeout 200 rocprofv3 --pmc SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS --kernel-trace -f csv -d $O/abl16b_$abl -o c -- python $R/scripts/bench_conv.py --batch 4 --io16 --only 'body 64->64 @1280' --iters 6 > $O/abl16b_$abl.log 2>&1
+                  python $R/scripts/pmc_kernel.py $O/abl16b_$abl conv3x3_split_kernel >> $O/abl16_pmc.txt 2>&1
+                  rm -rf $O/abl16_$abl $O/abl16b_$abl
+                done
+                cd $R ;;
+    test_head)  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "head" 2>&1 | tail -60 > $O/pytest_head.log ;;
+    bench_head) (timeout 200 python scripts/bench_conv.py --only "dcn head"; echo "== C2M_HEAD_QUAD=0"; C2M_HEAD_QUAD=0 timeout 200 python scripts/bench_conv.py --only "dcn head") > $O/bench_head.log 2>&1 ;;
     test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;

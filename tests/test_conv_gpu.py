@@ -496,7 +496,9 @@ def test_dcn_head_on_the_split_kernel(ops, dev, algo):
     import c2m_oracle as oracle
     import synth
     B, C, dg = 2, 64, 8
-    for (h, w, s) in ((12, 14, 1), (12, 16, 2), (12, 16, 4)):
+    # W % 4 != 0: dword planar stores; W % 4 == 0: the quad-transposed 16-byte stores with the per-row flow window (every
+    # scale; ragged tiles in x and y; windows that cross 32-pixel tile boundaries)
+    for (h, w, s) in ((12, 14, 1), (12, 16, 2), (12, 16, 4), (11, 16, 1), (9, 44, 1), (13, 22, 2), (7, 19, 4), (10, 40, 4)):
         H, W = h * s, w * s
         feat = _cl(_rand((B, C, H, W), dev, 360 + s))
         wt, bs = _rand((3 * dg * 9, C, 3, 3), dev, 361, 0.02), _rand((3 * dg * 9,), dev, 362, 0.1)
@@ -515,6 +517,39 @@ def test_dcn_head_on_the_split_kernel(ops, dev, algo):
         assert float((off.double() - (want_off + pre_t)).abs().max()) < tol
         assert float((msk.double() - torch.sigmoid(m)).abs().max()) < 1e-6
         assert abs(float(abs_sum.sum()) - want_abs) < 1e-4 * want_abs
+
+
+@pytest.mark.parametrize("algo", ["split16", "split"])
+def test_dcn_head_store_paths_are_bit_identical_at_full_size(ops, dev, algo):
+    """The quad-transposed 16-byte stores + register flow window against the dword stores + per-pixel flow loads on a chip-filling
+    launch (two resident workgroups per CU, ~59 M values per call, repeated): every offset and mask bit equal.  (A staged
+    version of these stores was withdrawn in round 4 for a one-in-10^6 corruption that only full-size launches showed.)"""
+    import synth
+    B, C, dg, s, h = 8, 64, 8, 4, 160
+    H = W = h * s
+    feat = _cl(_rand((B, C, H, W), dev, 380))
+    wt, bs = _rand((3 * dg * 9, C, 3, 3), dev, 381, 0.02), _rand((3 * dg * 9,), dev, 382, 0.1)
+    hp = h - 2
+    idx = (synth.uniform((B, hp, hp), 383, 0.0, 1.0).astype(np.float64) * (hp * hp)).astype(np.int64) % (hp * hp)
+    flow = ops.index_to_flow(torch.from_numpy(idx).to(dev))
+    with ops.head_store_mode(0):
+        a0 = torch.zeros(256, dtype=torch.float64, device=dev)
+        off0, msk0 = ops.conv3x3_dcn_head(feat, wt, bs, dg, flow, s, a0, algo=algo)
+    for rep in range(3):
+        with ops.head_store_mode(1):
+            a1 = torch.zeros(256, dtype=torch.float64, device=dev)
+            off1, msk1 = ops.conv3x3_dcn_head(feat, wt, bs, dg, flow, s, a1, algo=algo)
+        assert torch.equal(off0, off1) and torch.equal(msk0, msk1), rep
+        assert abs(float(a0.sum()) - float(a1.sum())) <= 1e-9 * float(a0.sum())
+        del off1, msk1
+    # the medium stage (scale 2, 128 -> 216): two sources
+    f2a, f2b = _cl(_rand((B, 64, 320, 320), dev, 384)), _cl(_rand((B, 64, 320, 320), dev, 385))
+    w2, b2 = _rand((3 * dg * 9, 128, 3, 3), dev, 386, 0.02), _rand((3 * dg * 9,), dev, 387, 0.1)
+    with ops.head_store_mode(0):
+        r0 = ops.conv3x3_dcn_head([f2a, f2b], w2, b2, dg, flow, 2, None, algo=algo)
+    with ops.head_store_mode(1):
+        r1 = ops.conv3x3_dcn_head([f2a, f2b], w2, b2, dg, flow, 2, None, algo=algo)
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
 
 
 def test_weight_cache_refresh_follows_data_writes(ops, dev):
