@@ -70,6 +70,10 @@ def _declare(L):
     L.c2m_conv3x3_rgb64_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _i, _i,
                                         ctypes.c_longlong, _vp, _i, ctypes.c_longlong, ctypes.c_longlong]
     L.c2m_dcn_v2_forward_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_float, _i]
+    L.c2m_dcn_v2_relayout_f16x2_bytes.restype = _sz
+    L.c2m_dcn_v2_relayout_f16x2_bytes.argtypes = [_i] * 5
+    L.c2m_dcn_v2_relayout_f16x2.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp]
+    L.c2m_dcn_v2_forward_nhwc_f16x2.argtypes = [_vp] * 6 + [_i] * 14 + [_vp, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_float, _i, _vp]
     L.c2m_conv3x3_relayout_bytes.restype = _sz
     L.c2m_conv3x3_relayout_bytes.argtypes = [_i, _i]
     L.c2m_conv3x3_relayout_f32.argtypes = [_vp, _vp, _i, _i, _vp]

@@ -492,6 +492,8 @@ _SPLIT = _os.environ.get("C2M_CONV_SPLIT", "all")
 # domain |x| < 65520: include/c2m_hip.h C2M_CONV_SPLIT_F16X2); "0" -- the bf16 x 3 flavour (full fp32 range) everywhere.
 # The autograd path (conv3x3_autograd: gradients can be tiny) always runs bf16 x 3.
 _SPLIT16 = _os.environ.get("C2M_CONV_SPLIT16", "1") != "0"
+# C2M_DCN_F16X2: "1" (default) -- the DCNv2 forward's implicit GEMM follows the convolutions onto the f16 x 2 arithmetic
+_DCN_F16X2 = _os.environ.get("C2M_DCN_F16X2", "1") != "0"
 # internal kernel ids (= weight-cache kinds; 5 is the data-gradient image of the bf16 x 3 kernel) -> c2m_conv3x3_desc.algo
 ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4, "split16": 6}
 _DESC_ALGO = (0, 1, 2, 3, 4, 3, 5)
@@ -989,13 +991,29 @@ class _DcnWeightCache(_WeightCache):
             _lib.check(L.c2m_dcn_v2_relayout_f32(_stream(), w.data_ptr(), C, Co, kh, kw, dg, wt.data_ptr()), "c2m_dcn_v2_relayout_f32")
         return wt
 
-    def get(self, weight, dg):
+    @staticmethod
+    def _relayout_dcn16(weight, dg, wt=None):
+        w = _dev_f32(weight.detach(), "weight")
+        Co, C, kh, kw = w.shape
+        L = _lib.lib()
+        nbytes = L.c2m_dcn_v2_relayout_f16x2_bytes(C, Co, kh, kw, dg)
+        if nbytes == 0:
+            raise _lib.C2MError("dcn_v2_forward_nhwc: geometry has no f16 x 2 kernel (needs >= 16 channels per (virtual) group)")
+        if wt is None:
+            wt = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(L.c2m_dcn_v2_relayout_f16x2(_stream(), w.data_ptr(), C, Co, kh, kw, dg, wt.data_ptr()), "c2m_dcn_v2_relayout_f16x2")
+        return wt
+
+    def get(self, weight, dg, f16x2=False):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), dg, weight.device.index)
-        hit = self._lookup(id(weight), key, weight)
+        slot = (id(weight), None, "dcn16") if f16x2 else id(weight)
+        hit = self._lookup(slot, key, weight)
         if hit is not None:
             return hit
-        wt = self._relayout_dcn(weight, dg)
-        self._store(id(weight), key, weight, wt, redo=lambda w, buf, dg=dg: self._relayout_dcn(w, dg, buf))
+        fn = self._relayout_dcn16 if f16x2 else self._relayout_dcn
+        wt = fn(weight, dg)
+        self._store(slot, key, weight, wt, redo=lambda w, buf, dg=dg, fn=fn: fn(w, dg, buf))
         return wt
 
 
@@ -1028,10 +1046,19 @@ def clear_weight_caches():
     _dcn_wcache.clear()
 
 
+def dcn_f16x2_ok(weight, deformable_groups):
+    Co, C, kh, kw = weight.shape
+    return _lib.lib().c2m_dcn_v2_relayout_f16x2_bytes(C, Co, kh, kw, int(deformable_groups)) != 0
+
+
 def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_groups, act=ACT_NONE, slope=0.1,
-                        nhwc_out=True):
+                        nhwc_out=True, algo=None):
     """3x3 / stride 1 / pad 1 DCNv2 forward from a BorderedNHWC input; planar offset / mask as dcn_v2_forward takes them.
-    -> channels_last [B,Co,H,W] (nhwc_out) or contiguous NCHW, with the activation applied."""
+    -> channels_last [B,Co,H,W] (nhwc_out) or contiguous NCHW, with the activation applied.
+    algo: "fp32" (implicit GEMM on the fp32 matrix pipe), "f16x2" (fp32 result on the f16 pipe, three products per k step:
+    the convolutions' f16 x 2 arithmetic, domain |sample| < 65520 reported through the same range flag), None: f16 x 2
+    wherever the convolutions of this thread currently run it (ops.conv_flavour / f16_range_guard / $C2M_CONV_SPLIT16,
+    $C2M_DCN_F16X2=0 keeps fp32) and the geometry has that kernel."""
     if not isinstance(inp_bordered, BorderedNHWC):
         raise _lib.C2MError("inp_bordered must be a BorderedNHWC")
     B, C, H, W = inp_bordered.B, inp_bordered.C, inp_bordered.H, inp_bordered.W
@@ -1040,7 +1067,13 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     offset, mask, bias = _dev_f32(offset, "offset"), _dev_f32(mask, "mask"), _dev_f32(bias.detach(), "bias")
     if tuple(offset.shape) != (B, 2 * dg * 9, H, W) or tuple(mask.shape) != (B, dg * 9, H, W):
         raise _lib.C2MError("offset/mask shape does not match [B, 2*dg*9, H, W] / [B, dg*9, H, W]")
-    wt = _dcn_wcache.get(weight, dg)
+    if algo is None:
+        f16 = _DCN_F16X2 and _SPLIT != "0" and _split16_now() and not bf16_autocast() and dcn_f16x2_ok(weight, dg)
+    elif algo in ("fp32", "f16x2"):
+        f16 = algo == "f16x2"
+    else:
+        raise _lib.C2MError("dcn_v2_forward_nhwc: algo is None, 'fp32' or 'f16x2'")
+    wt = _dcn_wcache.get(weight, dg, f16x2=f16)
     dev = offset.device
     if nhwc_out:
         out = empty_nhwc(B, Co, H, W, dev)
@@ -1052,11 +1085,18 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     grouped = inp_bordered.grouped8 is not None and C == 8 * dg
     src = inp_bordered.grouped8 if grouped else inp_bordered.buf
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f32(_stream(), src.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                                         offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1, 1,
-                                                         1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope),
-                                                         int(grouped)),
-                   "c2m_dcn_v2_forward_nhwc_f32")
+        if f16:
+            _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f16x2(_stream(), src.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                               offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1,
+                                                               1, 1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope),
+                                                               int(grouped), _range_flag(dev).data_ptr()),
+                       "c2m_dcn_v2_forward_nhwc_f16x2")
+        else:
+            _lib.check(_lib.lib().c2m_dcn_v2_forward_nhwc_f32(_stream(), src.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                             offset.data_ptr(), mask.data_ptr(), B, C, H, W, Co, 3, 3, 1, 1, 1, 1,
+                                                             1, 1, dg, out.data_ptr(), *pitches, int(act), float(slope),
+                                                             int(grouped)),
+                       "c2m_dcn_v2_forward_nhwc_f32")
     return out
 
 

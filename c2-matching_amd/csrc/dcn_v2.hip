@@ -49,6 +49,7 @@ struct Geom {
   // (pixel, group, corner) on its own 128-byte line, group-major puts the two horizontal corners and the neighbouring
   // pixels' samples of a coherent flow on shared lines (large layer, B=16: 7.6 -> 5.9 ms).
   int in_grouped;
+  int* range_flag;   // f16 x 2 GEMM: set to 1 when an output is not finite (a blended sample left |x| < 65520), or nullptr
 };
 
 // bilinear sampling state of one (pixel, group, tap)
@@ -177,6 +178,49 @@ __global__ void __launch_bounds__(256) weight_relayout_bf16_kernel(const float* 
   const int tap = gs / g.dg, grp = gs - tap * g.dg;
   const int cig = ((pos >> 3) & 1) * (g.CPG / 2) + 8 * (pos >> 4) + (pos & 7);
   wh[e] = (__bf16)(o < g.Co ? w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap] : 0.0f);
+}
+
+// f16 x 2 weights of the channels-last forward kernel (fp32 result on the f16 matrix pipe, as C2M_CONV_SPLIT_F16X2): S w =
+// wA + w1 with the per-tensor power of two S that puts max |w| into [2^14, 2^15); Wh[K/8][2 pieces][CoPad][8] f16 in the K
+// order of weight_relayout_bf16_kernel, then one float 1/S at element K*CoPad (in floats) of the image.
+__global__ void __launch_bounds__(1024) weight_absmax_kernel(const float* __restrict__ w, int n, float* __restrict__ sinv_out) {
+  __shared__ unsigned red[1024];
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float wmax = __uint_as_float(red[0]);
+    float S = 1.0f;
+    if (wmax > 0.0f && wmax <= 3.0e38f) {
+      int e;
+      (void)frexpf(wmax, &e);
+      e = 15 - e;
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+      S = ldexpf(1.0f, e);
+    }
+    *sinv_out = 1.0f / S;   // (power of two: exact)
+  }
+}
+__global__ void __launch_bounds__(256) weight_relayout_f16x2_kernel(const float* __restrict__ w, Geom g, const float* __restrict__ sinv,
+                                                                     _Float16* __restrict__ wh) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= g.CoPad * g.Ktot) return;
+  const int k8 = e / (g.CoPad * 8), r = e - k8 * (g.CoPad * 8);
+  const int o = r >> 3, k = k8 * 8 + (r & 7);
+  const int gs = k / g.CPG, pos = k - gs * g.CPG;
+  const int tap = gs / g.dg, grp = gs - tap * g.dg;
+  const int cig = ((pos >> 3) & 1) * (g.CPG / 2) + 8 * (pos >> 4) + (pos & 7);
+  const float S = 1.0f / *sinv;
+  const float v = (o < g.Co ? w[((size_t)o * g.C + grp * g.CPG + cig) * g.T + tap] : 0.0f) * S;   // exact (power of two)
+  const _Float16 a = (_Float16)v;
+  const size_t base = ((size_t)k8 * 2 * g.CoPad + o) * 8 + (r & 7);
+  wh[base] = a;
+  wh[base + (size_t)g.CoPad * 8] = (_Float16)(v - (float)a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -357,8 +401,16 @@ __global__ void __launch_bounds__(256) nchw_to_grouped_kernel(const float* __res
 //   * BF16: the GEMM runs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): `wt` then points to bf16 weights laid out
 //     [K/8][CoPad][8] (weight_relayout_bf16_kernel), the blended column values are rounded to bf16 (RNE) in registers.
 //     Gathers, sampling state and blend stay fp32.  For callers that ask for reduced precision (bf16 autocast).
-template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
-__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16 && MT <= 2) ? 4 : 2)) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
+//   * F16X2: the GEMM runs on v_mfma_f32_32x32x16_f16 with THREE products per k step (the arithmetic of the convolutions'
+//     C2M_CONV_SPLIT_F16X2): the blended fp32 column value c = x0 + 2^-11 x1' (two round-to-nearest f16 pieces), the scaled
+//     weight S w = wA + w1 (weight_relayout_f16x2_kernel); S w.c = wA.x0 + w1.x0 + (2^-11 wA).x1', one accumulator, times 1/S
+//     in the epilogue.  3/32 of the fp32 pipe's matrix time; gathers, sampling state and blend as the fp32 kernel.  Domain
+//     |c| < 65520 -- beyond it the output is not finite, which the epilogue reports into Geom::range_flag.
+#ifndef C2M_DCN_F16_OCC
+#define C2M_DCN_F16_OCC 3
+#endif
+template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16, bool F16X2 = false>
+__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16 && MT <= 2) ? (F16X2 ? C2M_DCN_F16_OCC : 4) : 2)) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
@@ -369,7 +421,8 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16
   constexpr int NQ = HALF / EPV;              // gathers per corner
   constexpr int MW = MT * 32;                 // output channels of this workgroup
   constexpr int CHUNK = GC * CPG * MW / (BF16 ? 2 : 1);   // floats (4-byte units) per weight chunk
-  static_assert(!BF16 || HALF % 8 == 0, "a bf16 MFMA takes 8 channels from each half-wave");
+  static_assert(!(BF16 || F16X2) || HALF % 8 == 0, "a 16-bit MFMA takes 8 channels from each half-wave");
+  static_assert(!(BF16 && F16X2), "one GEMM arithmetic");
   extern __shared__ __attribute__((aligned(16))) float wl[];  // fp32: [2][GC*CPG][MW]; bf16: [2][GC*CPG/8][MW][8]
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,13 +477,13 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16
   // (bf16: rows are k octets, one 16-byte piece per (octet, output channel))
   auto stage = [&](int ci, int buf) {   // 16-byte pieces, 64 per DMA instruction (wave-uniform LDS base + lane*16)
     constexpr int NPIECE = CHUNK / 4;
-    constexpr int PPR = BF16 ? MW : MW / 4;            // pieces per row
-    constexpr int ROWS = BF16 ? GC * CPG / 8 : GC * CPG;
+    constexpr int PPR = (BF16 || F16X2) ? MW : MW / 4;            // pieces per row
+    constexpr int ROWS = BF16 ? GC * CPG / 8 : F16X2 ? 2 * GC * CPG / 8 : GC * CPG;   // (f16 x 2: a row per (k octet, piece))
     for (int pb = wv * 64; pb < NPIECE; pb += 256) {
       const int piece = pb + l;
       if (piece < NPIECE) {
         const int row = piece / PPR, pc_ = piece - row * PPR;
-        const float* src = wt + ((size_t)(ci * ROWS + row) * g.CoPad + ob * MW) * (BF16 ? 4 : 1) + pc_ * 4;
+        const float* src = wt + ((size_t)(ci * ROWS + row) * g.CoPad + ob * MW) * ((BF16 || F16X2) ? 4 : 1) + pc_ * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(wl + buf * CHUNK + pb * 4), 16, 0, 0);
       }
@@ -586,6 +639,45 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vb[nt], acc[mt][nt], 0, 0, 0);
         }
       }
+    } else if constexpr (F16X2) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+      // A operands of (m, mt): pieces wA / w1 of k octet (gi*CPG/8 + 2m + hi), output channel mt*32 + j
+      const f16x8* wrow = reinterpret_cast<const f16x8*>(wl + (ci & 1) * CHUNK) + (size_t)((gi * (CPG / 8) + hi) * 2) * MW + j;
+#pragma unroll
+      for (int m = 0; m < HALF / 8; ++m) {
+        f16x8 b0[NT], b1[NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // channel pairs (8m + 2u, 8m + 2u + 1): packed blend as the fp32 kernel, then the split
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int ch = 8 * m + 2 * u;
+            const f32x4 q1 = gvA[nt].v1[ch >> 2], q2 = gvA[nt].v2[ch >> 2], q3 = gvA[nt].v3[ch >> 2], q4 = gvA[nt].v4[ch >> 2];
+            const int e = ch & 3;
+            const f32x2 a1 = {q1[e], q1[e + 1]}, a2 = {q2[e], q2[e + 1]}, a3 = {q3[e], q3[e + 1]}, a4 = {q4[e], q4[e + 1]};
+            const f32x2 k1 = {wA[nt].w1, wA[nt].w1}, k2 = {wA[nt].w2, wA[nt].w2}, k3 = {wA[nt].w3, wA[nt].w3},
+                        k4 = {wA[nt].w4, wA[nt].w4};
+            const f32x2 c = __builtin_elementwise_fma(k4, a4, __builtin_elementwise_fma(k3, a3, __builtin_elementwise_fma(k2, a2, k1 * a1)));
+            const f16x2v h0 = __builtin_convertvector(c, f16x2v);
+            const f32x2 r = (c - __builtin_convertvector(h0, f32x2)) * 2048.0f;
+            const f16x2v h1 = __builtin_convertvector(r, f16x2v);
+            b0[nt][2 * u] = h0[0]; b0[nt][2 * u + 1] = h0[1];
+            b1[nt][2 * u] = h1[0]; b1[nt][2 * u + 1] = h1[1];
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f16x8 a0 = wrow[(size_t)(2 * m) * 2 * MW + mt * 32], a1 = wrow[(size_t)((2 * m) * 2 + 1) * MW + mt * 32];
+          const f16x8 ad = a0 * (_Float16)(1.0f / 2048.0f);   // (exact unless subnormal: weights below 2^-13 max |w|, lost bits ~2^-39 of the largest product)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, b1[nt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      }
     } else {
     // MFMAs: A[i = o][kk] from the staged chunk, row (2t + hi) of group gi, column mt*32 + j
     const float* wrow = wl + (ci & 1) * CHUNK + j + (gi * CPG + hi) * MW;
@@ -661,6 +753,21 @@ __global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16
     }
   }
 
+  if constexpr (F16X2) {
+    // times 1/S (a power of two: exact); an output that is not finite means a blended sample left the f16 x 2 domain
+    const float sinv = wt[(size_t)g.Ktot * g.CoPad];
+    bool bad = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[mt][nt][r] *= sinv;
+          bad |= !(fabsf(acc[mt][nt][r]) <= 3.0e38f);
+        }
+    if (bad && g.range_flag != nullptr) *g.range_flag = 1;   // (rare, idempotent)
+  }
   if (g.out_nhwc) {
     // channels-last store (+ activation): the lane's rows (r & 3) are 4 consecutive output channels = one float4
 #pragma unroll
@@ -1245,6 +1352,7 @@ int make_geom(Geom& g, int B, int C, int H, int W, int Co, int kh, int kw, int s
   g.B = B; g.C = C; g.H = H; g.W = W; g.Co = Co; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
   g.dh = dh; g.dw = dw; g.dg = dg;
   g.in_grouped = 0;
+  g.range_flag = nullptr;
   g.out_nhwc = 0; g.out_pix_pitch = 0; g.out_row_pitch = 0; g.out_img_pitch = 0; g.act = 0; g.slope = 0.0f;
   g.Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
   g.Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
@@ -1267,38 +1375,38 @@ inline int copad_fwd(int Co) {
 }
 inline int copad2(int Co) { return Co <= 64 ? 64 : Co <= 128 ? 128 : Co <= 256 ? 256 : -1; }
 
-template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16>
+template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16, bool F16X2>
 int launch_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                     const float* msk, const Geom& g, float* out) {
   const int HWo = g.Ho * g.Wo;
   const size_t lds = (BF16 ? 2 : 4) * 2 * (size_t)GC * CPG * MT * 32;
   static unsigned long long lds_set = 0;
   if (lds > 48 * 1024)
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16>), lds, lds_set))
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16, F16X2>), lds, lds_set))
       return rc;
   dim3 grid(ceil_div(HWo, 4 * NT * 32), g.B, g.CoPad / (MT * 32));
-  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
+  hipLaunchKernelGGL((dcn::dcn_fwd_nhwc_kernel<MT, NT, CPG, GC, SPLITG, BF16, F16X2>), grid, dim3(256), lds, st, inl, wt, bias, off, msk, g, out);
   return C2M_OK;
 }
 
 // groups per weight chunk: the largest power of two dividing dg with chunk <= 32 KiB (and >= 4 KiB so that every wave's
 // quarter is a whole number of 1 KiB DMA pieces)
-template <int MT, int NT, int CPG, bool SPLITG, bool BF16>
+template <int MT, int NT, int CPG, bool SPLITG, bool BF16, bool F16X2>
 int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                      const float* msk, const Geom& g, float* out) {
   constexpr int ROWB = CPG * MT * 32 * (BF16 ? 2 : 4);  // bytes of one group's weight rows
   constexpr int FIT = ((MT == 8 ? 64 : 32) * 1024) / ROWB;  // groups that fit a 32 KiB chunk (64 KiB for the one-wave-per-SIMD MT = 8 variant)
   if constexpr (FIT >= 8) {
-    if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
   }
   if constexpr (FIT >= 4) {
-    if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    if (g.dg % 4 == 0) return launch_fwd_nhwc<MT, NT, CPG, 4, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
   }
   static_assert(FIT >= 2, "two groups' weight rows must fit one chunk");
-  return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);   // use_nhwc() guarantees an even dg
+  return launch_fwd_nhwc<MT, NT, CPG, 2, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);   // use_nhwc() guarantees an even dg
 }
 
-template <int CPG, bool SPLITG, bool BF16>
+template <int CPG, bool SPLITG, bool BF16, bool F16X2 = false>
 int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt, const float* bias, const float* off,
                       const float* msk, const Geom& g, float* out) {
   // Register budget (256 VGPRs at 2 waves/SIMD): MT*NT*16 accumulators + two generations of gathered corners
@@ -1308,14 +1416,14 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
   // latency better than a second pixel tile amortises the LDS weight reads (large layer, B=16: 10.4 -> 8.4 ms)
   constexpr int NT2 = 1;
   switch (mt) {
-    case 1: return pick_gc_fwd_nhwc<1, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
-    case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    case 1: return pick_gc_fwd_nhwc<1, NT2, CPG, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
+    case 2: return pick_gc_fwd_nhwc<2, NT2, CPG, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
     case 8:
       // bf16: the kernel is gather/blend bound, so all 256 output channels share one gathered column (one wave per SIMD,
       // 128 accumulator registers) instead of splitting Co over grid.z and gathering twice.  (fp32: measured, no gain.)
-      if constexpr (BF16 && CPG == 32) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+      if constexpr (BF16 && CPG == 32) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, BF16, false>(st, inl, wt, bias, off, msk, g, out);
       [[fallthrough]];
-    default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16>(st, inl, wt, bias, off, msk, g, out);
+    default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
   }
 }
 
@@ -1369,6 +1477,8 @@ struct FwdExt {
   int out_nhwc = 0, out_pix_pitch = 0, out_row_pitch = 0, act = 0;
   long long out_img_pitch = 0;
   float slope = 0.0f;
+  int f16x2 = 0;                // `wt` holds the f16 x 2 image (c2m_dcn_v2_relayout_f16x2): GEMM on the f16 matrix pipe
+  int* range_flag = nullptr;
 };
 
 int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, const float* bias, const float* offset,
@@ -1388,6 +1498,7 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
     return C2M_ERR_UNSUPPORTED;
   g.out_nhwc = ext.out_nhwc; g.out_pix_pitch = ext.out_pix_pitch; g.out_row_pitch = ext.out_row_pitch;
   g.out_img_pitch = ext.out_img_pitch; g.act = ext.act; g.slope = ext.slope;
+  g.range_flag = ext.range_flag;
   const size_t wbytes = ext.wt ? 0 : align256(sizeof(float) * (size_t)g.KtotPad * g.CoPad);
   const size_t need = wbytes + ((nhwc && !ext.inl) ? align256(sizeof(float) * (size_t)B * C * (H + 3) * (W + 3)) : 0);
   if (need > 0 && (!workspace || workspace_bytes < need)) return C2M_ERR_WORKSPACE;
@@ -1419,9 +1530,15 @@ int dcn_forward(c2m_stream_t stream, const float* input, const float* weight, co
                          nhwc ? 1 : 0, wt, (float*)nullptr);
   }
   if ((rc = check_launch()) != C2M_OK) return rc;
+  if (ext.f16x2 && (!ext.wt || !nhwc || gk.CPG < 16)) return C2M_ERR_UNSUPPORTED;
+  gk.range_flag = g.range_flag;
   if (nhwc) {
     ProfileScope prof(C2M_KERNEL_DCN_FWD, st);
-    if (bf16) {
+    if (ext.f16x2) {
+      if (split) rc = dispatch_fwd_nhwc<16, true, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, gk, output);
+      else if (g.CPG == 16) rc = dispatch_fwd_nhwc<16, false, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
+      else rc = dispatch_fwd_nhwc<32, false, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
+    } else if (bf16) {
       if (split) rc = dispatch_fwd_nhwc<16, true, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, gk, output);
       else if (g.CPG == 16) rc = dispatch_fwd_nhwc<16, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
       else rc = dispatch_fwd_nhwc<32, false, true>(st, fwd_mt(Co), inl, wt, bias, offset, mask, g, output);
@@ -1483,6 +1600,49 @@ extern "C" int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* inp
   FwdExt ext;
   ext.inl = input_bordered; ext.in_grouped = input_grouped; ext.wt = wt; ext.out_nhwc = out_nhwc; ext.out_pix_pitch = out_pix_pitch;
   ext.out_row_pitch = out_row_pitch; ext.out_img_pitch = out_img_pitch; ext.act = act; ext.slope = slope;
+  return dcn_forward(stream, nullptr, nullptr, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
+                     nullptr, 0, false, ext);
+}
+
+// ---- f16 x 2 GEMM (channels-last path, >= 16 channels per -- possibly virtual -- group)
+static bool f16x2_geom(Geom& g, Geom& gk, int C, int Co, int kh, int kw, int dg) {
+  if (make_geom(g, 1, C, 8, 8, Co, kh, kw, 1, 1, kh / 2, kw / 2, 1, 1, dg) != C2M_OK || !use_nhwc(g)) return false;
+  g.CoPad = copad_fwd(Co);
+  gk = g;
+  if (g.CPG == 8 && g.dg % 4 == 0) { gk.CPG = 2 * g.CPG; gk.dg = g.dg / 2; }
+  return gk.CPG >= 16 && g.Ktot % 16 == 0;
+}
+
+extern "C" size_t c2m_dcn_v2_relayout_f16x2_bytes(int C, int Co, int kh, int kw, int dg) {
+  Geom g, gk;
+  if (!f16x2_geom(g, gk, C, Co, kh, kw, dg)) return 0;
+  return (size_t)g.Ktot * g.CoPad * 4 + 256;   // two f16 pieces per weight + the float 1/S behind them
+}
+
+extern "C" int c2m_dcn_v2_relayout_f16x2(c2m_stream_t stream, const float* weight, int C, int Co, int kh, int kw, int dg,
+                                         void* wt) {
+  if (!weight || !wt) return C2M_ERR_INVALID_ARG;
+  Geom g, gk;
+  if (!f16x2_geom(g, gk, C, Co, kh, kw, dg)) return C2M_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  float* sinv = static_cast<float*>(wt) + (size_t)g.Ktot * g.CoPad;
+  const long long n = (long long)Co * C * kh * kw;
+  if (n > 0x7fffffffLL) return C2M_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(dcn::weight_absmax_kernel, dim3(1), dim3(1024), 0, st, weight, (int)n, sinv);
+  hipLaunchKernelGGL(dcn::weight_relayout_f16x2_kernel, dim3(ceil_div(g.CoPad * g.Ktot, 256)), dim3(256), 0, st, weight, gk, sinv,
+                     static_cast<_Float16*>(wt));
+  return check_launch();
+}
+
+extern "C" int c2m_dcn_v2_forward_nhwc_f16x2(c2m_stream_t stream, const float* input_bordered, const void* wt,
+                                             const float* bias, const float* offset, const float* mask, int B, int C, int H,
+                                             int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                             int dg, float* output, int out_nhwc, int out_pix_pitch, int out_row_pitch,
+                                             long long out_img_pitch, int act, float slope, int input_grouped, int* range_flag) {
+  FwdExt ext;
+  ext.inl = input_bordered; ext.in_grouped = input_grouped; ext.wt = static_cast<const float*>(wt); ext.out_nhwc = out_nhwc;
+  ext.out_pix_pitch = out_pix_pitch; ext.out_row_pitch = out_row_pitch; ext.out_img_pitch = out_img_pitch; ext.act = act;
+  ext.slope = slope; ext.f16x2 = 1; ext.range_flag = range_flag;
   return dcn_forward(stream, nullptr, nullptr, bias, offset, mask, B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, output,
                      nullptr, 0, false, ext);
 }

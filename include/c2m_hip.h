@@ -182,6 +182,23 @@ int c2m_dcn_v2_forward_nhwc_f32(c2m_stream_t stream, const float* input_bordered
                                 int out_pix_pitch, int out_row_pitch, long long out_img_pitch, int act, float slope,
                                 int input_grouped);
 
+/*
+ * The same forward with the implicit GEMM on the F16 matrix pipe, fp32 result (the arithmetic of C2M_CONV_SPLIT_F16X2: the
+ * blended column value c = x0 + 2^-11 x1' in two round-to-nearest f16 pieces, per-tensor-scaled weights S w = wA + w1, three
+ * products per k step, one fp32 accumulator, times 1/S): 3/32 of the fp32 pipe's matrix time, error of the class of the fp32
+ * accumulation chain.  Geometries with >= 16 channels per (virtual) group, i.e. every DynAgg layer of the restoration network
+ * (c2m_dcn_v2_relayout_f16x2_bytes == 0 otherwise).  Domain: |mask * bilinear sample| < 65520 -- beyond it outputs are not
+ * finite and `range_flag` (device int, may be NULL; never cleared here) is set to 1: the caller recomputes with
+ * c2m_dcn_v2_forward_nhwc_f32, as for the convolutions (c2m_conv3x3_desc.range_flag).
+ */
+size_t c2m_dcn_v2_relayout_f16x2_bytes(int C, int Co, int kh, int kw, int dg);
+int c2m_dcn_v2_relayout_f16x2(c2m_stream_t stream, const float* weight, int C, int Co, int kh, int kw, int dg, void* wt);
+int c2m_dcn_v2_forward_nhwc_f16x2(c2m_stream_t stream, const float* input_bordered, const void* wt, const float* bias,
+                                  const float* offset, const float* mask, int B, int C, int H, int W, int Co, int kh, int kw,
+                                  int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* output, int out_nhwc,
+                                  int out_pix_pitch, int out_row_pitch, long long out_img_pitch, int act, float slope,
+                                  int input_grouped, int* range_flag);
+
 size_t c2m_dcn_v2_backward_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph,
                                            int pw, int dh, int dw, int dg);
 /* All gradients are OVERWRITTEN (the reference starts them from zeros, dcn_v2_cuda.cu:251-255).  grad_input may be NULL:

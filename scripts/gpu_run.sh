@@ -63,6 +63,9 @@ PY
                 cd $R ;;
     test_head)  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "head" 2>&1 | tail -60 > $O/pytest_head.log ;;
     bench_head) (timeout 200 python scripts/bench_conv.py --only "dcn head"; echo "== C2M_HEAD_QUAD=0"; C2M_HEAD_QUAD=0 timeout 200 python scripts/bench_conv.py --only "dcn head") > $O/bench_head.log 2>&1 ;;
+    test_dcn16) timeout 900 python -m pytest tests/test_dcn_gpu.py -m gpu -q -x -k "f16x2" 2>&1 | tail -60 > $O/pytest_dcn16.log ;;
+    bench_dcn16) timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_dcn16_on.log 2>&1
+                C2M_DCN_F16X2=0 timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_dcn16_off.log 2>&1 ;;
     test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;

@@ -115,6 +115,86 @@ def test_forward_bf16_mma_matches_bf16_oracle(env, dev, shape):
                                rtol=0, atol=2e-5 * max(1.0, float(a.abs().max())))
 
 
+def _dcn_ref64(x, w, b, off, msk, dg):
+    """float64 DCNv2 forward (3x3, stride 1, pad 1) from torch primitives: bilinear sampling with zeros outside
+    (dcn_v2_im2col_cuda.cu:25-60: corners outside the image contribute nothing) = grid_sample(zeros, align_corners)."""
+    x, w, b, off, msk = (a.double() for a in (x, w, b, off, msk))
+    B, C, H, W = x.shape
+    cpg = C // dg
+    ys, xs = torch.meshgrid(torch.arange(H, device=x.device, dtype=torch.float64),
+                            torch.arange(W, device=x.device, dtype=torch.float64), indexing="ij")
+    cols = torch.zeros((B, C, 9, H, W), dtype=torch.float64, device=x.device)
+    for g in range(dg):
+        xg = x[:, g * cpg:(g + 1) * cpg]
+        for k in range(9):
+            py = ys - 1 + k // 3 + off[:, (g * 9 + k) * 2]
+            px = xs - 1 + k % 3 + off[:, (g * 9 + k) * 2 + 1]
+            grid = torch.stack((2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1), dim=-1)
+            smp = F.grid_sample(xg, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+            cols[:, g * cpg:(g + 1) * cpg, k] = smp * msk[:, g * 9 + k][:, None]
+    return torch.einsum("ock,bckhw->bohw", w.reshape(w.shape[0], C, 9), cols) + b[None, :, None, None]
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], (2, 32, 13, 15, 64, 3, 3, (1, 1), (1, 1), (1, 1), 2)])
+def test_forward_nhwc_f16x2_matches_oracle(env, dev, shape):
+    """The f16 x 2 implicit GEMM (fp32 result on the f16 matrix pipe: blended samples and scaled weights in two f16 pieces,
+    three products per k step) against the oracle, at the fp32 kernel's tolerance, and no further from a float64 evaluation
+    than the fp32-MFMA kernel is (x 1.5); channels-last output + activation; the cache refresh rebuilds its image."""
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = shape
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 320)
+    wt = torch.nn.Parameter(_t(w, dev))
+    args = (wt, _t(b, dev), _t(off, dev), _t(msk, dev), dg)
+    assert ops.dcn_f16x2_ok(wt, dg)
+    bo = ops.BorderedNHWC(_t(x, dev))
+    with torch.no_grad():
+        f32 = ops.dcn_v2_forward_nhwc(bo, *args, nhwc_out=False, algo="fp32")
+        f16 = ops.dcn_v2_forward_nhwc(bo, *args, nhwc_out=False, algo="f16x2")
+    want = oracle.dcn_v2_forward(x, w, b, off, msk, st, pd, dl, dg)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(f16.cpu().numpy(), want, rtol=0, atol=2e-5 * scale)
+    want64 = _dcn_ref64(*[_t(a, dev) for a in (x, w, b, off, msk)], dg)
+    assert float((want64 - _t(want, dev).double()).abs().max()) < 2e-5 * scale       # (the float64 restatement is the oracle's)
+    e16 = float((f16.double() - want64).abs().max()), float((f16.double() - want64).pow(2).mean().sqrt())
+    e32 = float((f32.double() - want64).abs().max()), float((f32.double() - want64).pow(2).mean().sqrt())
+    assert e16[1] <= 1.5 * e32[1] and e16[0] <= 2.0 * e32[0], (e16, e32)
+    assert not torch.equal(f16, f32)          # (it really ran the other arithmetic)
+    with torch.no_grad():
+        cl = ops.dcn_v2_forward_nhwc(bo, *args, act=ops.ACT_LRELU, slope=0.1, algo="f16x2")
+    np.testing.assert_allclose(cl.cpu().numpy(), np.where(want > 0, want, 0.1 * want), rtol=0, atol=2e-5 * scale)
+    if C == 8 * dg:                                     # group-major twin: the same arithmetic
+        bo.grouped8 = bo.buf.view(B, H + 3, W + 3, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+        with torch.no_grad():
+            assert torch.equal(ops.dcn_v2_forward_nhwc(bo, *args, nhwc_out=False, algo="f16x2"), f16)
+    # a .data write + refresh rebuilds the f16 x 2 image (scale included: the weights grow 1000-fold)
+    wt.data.mul_(1000.0)
+    ops.refresh_weight_caches([wt])
+    with torch.no_grad():
+        big = ops.dcn_v2_forward_nhwc(bo, wt, torch.zeros_like(args[1]), *args[2:], nhwc_out=False, algo="f16x2")
+        ref = ops.dcn_v2_forward_nhwc(bo, wt, torch.zeros_like(args[1]), *args[2:], nhwc_out=False, algo="fp32")
+    assert float((big - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_forward_nhwc_f16x2_reports_its_domain(env, dev):
+    """|mask * sample| >= 65520 leaves the f16 x 2 domain: the outputs are not finite there and the device range flag is set
+    (the fused forwards then recompute on the fp32 pipe: ops.f16_range_guard); in-range launches leave the flag alone."""
+    ops, oracle, synth = env
+    B, C, H, W, Co, kh, kw, st, pd, dl, dg = SHAPES[2]
+    x, w, b, off, msk = _case(synth, B, C, H, W, Co, kh, kw, st, pd, dl, dg, 330)
+    flag = ops._range_flag(torch.device(dev))
+    flag.zero_()
+    args = (_t(w, dev), _t(b, dev), _t(off, dev), _t(msk * 0 + 1, dev), dg)
+    ok = ops.dcn_v2_forward_nhwc(ops.BorderedNHWC(_t(x, dev)), *args, nhwc_out=False, algo="f16x2")
+    assert int(flag.item()) == 0 and bool(torch.isfinite(ok).all())
+    xb = x.copy()
+    xb[1, 5, 10:14, 8:12] = 3.0e5
+    bad = ops.dcn_v2_forward_nhwc(ops.BorderedNHWC(_t(xb, dev)), *args, nhwc_out=False, algo="f16x2")
+    assert int(flag.item()) == 1 and not bool(torch.isfinite(bad).all())
+    full = ops.dcn_v2_forward_nhwc(ops.BorderedNHWC(_t(xb, dev)), *args, nhwc_out=False, algo="fp32")
+    assert bool(torch.isfinite(full).all())
+    flag.zero_()
+
+
 def test_forward_zero_offset_is_conv2d(env, dev):
     ops, _, synth = env
     B, C, H, W, Co, dg = 2, 64, 20, 24, 64, 8
