@@ -409,8 +409,14 @@ __global__ void __launch_bounds__(256) nchw_to_grouped_kernel(const float* __res
 #ifndef C2M_DCN_F16_OCC
 #define C2M_DCN_F16_OCC 3
 #endif
+#ifndef C2M_DCN_F16_MT8
+#define C2M_DCN_F16_MT8 1   // 256 output channels share one gathered column (one wave per SIMD), as the bf16 GEMM does: the
+#endif                      // f16 x 2 kernel is gather bound (small layer, B=16: 4.27 -> 2.70 ms)
+#ifndef C2M_DCN_F16_OCC4
+#define C2M_DCN_F16_OCC4 2  // waves per SIMD asked of the MT = 4 f16 x 2 kernels
+#endif
 template <int MT, int NT, int CPG, int GC, bool SPLITG, bool BF16, bool F16X2 = false>
-__global__ void __launch_bounds__(256, (BF16 && MT == 8) ? 1 : ((SPLITG && !BF16 && MT <= 2) ? (F16X2 ? C2M_DCN_F16_OCC : 4) : 2)) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
+__global__ void __launch_bounds__(256, ((BF16 || F16X2) && MT == 8) ? 1 : ((SPLITG && !BF16 && MT <= 2) ? (F16X2 ? C2M_DCN_F16_OCC : 4) : ((F16X2 && MT == 4) ? C2M_DCN_F16_OCC4 : 2))) dcn_fwd_nhwc_kernel(const float* __restrict__ inl, const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ offset,
                                                                const float* __restrict__ mask, Geom g,
@@ -1395,7 +1401,11 @@ template <int MT, int NT, int CPG, bool SPLITG, bool BF16, bool F16X2>
 int pick_gc_fwd_nhwc(hipStream_t st, const float* inl, const float* wt, const float* bias, const float* off,
                      const float* msk, const Geom& g, float* out) {
   constexpr int ROWB = CPG * MT * 32 * (BF16 ? 2 : 4);  // bytes of one group's weight rows
-  constexpr int FIT = ((MT == 8 ? 64 : 32) * 1024) / ROWB;  // groups that fit a 32 KiB chunk (64 KiB for the one-wave-per-SIMD MT = 8 variant)
+#ifndef C2M_DCN_F16_CHUNK4_KB
+#define C2M_DCN_F16_CHUNK4_KB 32
+#endif
+  // groups that fit a 32 KiB chunk (64 KiB for the one-wave-per-SIMD MT = 8 variant)
+  constexpr int FIT = ((MT == 8 ? 64 : (F16X2 && MT == 4 && CPG == 16) ? C2M_DCN_F16_CHUNK4_KB : 32) * 1024) / ROWB;
   if constexpr (FIT >= 8) {
     if (g.dg % 8 == 0) return launch_fwd_nhwc<MT, NT, CPG, 8, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
   }
@@ -1422,6 +1432,7 @@ int dispatch_fwd_nhwc(hipStream_t st, int mt, const float* inl, const float* wt,
       // bf16: the kernel is gather/blend bound, so all 256 output channels share one gathered column (one wave per SIMD,
       // 128 accumulator registers) instead of splitting Co over grid.z and gathering twice.  (fp32: measured, no gain.)
       if constexpr (BF16 && CPG == 32) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, BF16, false>(st, inl, wt, bias, off, msk, g, out);
+      if constexpr (F16X2 && CPG == 32 && C2M_DCN_F16_MT8 != 0) return pick_gc_fwd_nhwc<8, 1, CPG, SPLITG, false, true>(st, inl, wt, bias, off, msk, g, out);
       [[fallthrough]];
     default: return pick_gc_fwd_nhwc<4, 1, CPG, SPLITG, BF16, F16X2>(st, inl, wt, bias, off, msk, g, out);
   }
