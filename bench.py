@@ -597,7 +597,7 @@ def main():
         if dk and len(dk) % 3 == 0:   # launch order inside a step: small, medium, large (ref_restoration_arch.py:152-180)
             dtraf = sorted(pmc.get("dcn_v2_forward_hbm_bytes_per_launch", {}).values())   # small < medium < large
             from c2m_amd import ops as _o
-            d16 = bool(_o._DCN_F16X2 and _o._SPLIT16 and _o._SPLIT != "0" and not bf16)
+            d16 = bool(_o._DCN_F16X2 and _o._SPLIT16 and _o._SPLIT != "0")
             for k, (lname, ch, hh) in enumerate(layers):
                 mine = dk[k::3]
                 rl.append(dcn_roofline(lname, B, ch, ch, hh, sum(mine) / len(mine), len(mine),

@@ -555,7 +555,9 @@ def f16_range_guard(owner, fn, device):
     `owner` (an nn.Module or any object) remembers the pinned flavour in `owner._c2m_conv_bf16x3`."""
     if getattr(_tls, "guarded", False):      # an enclosing guard (a parent module's forward) checks the flag for all of us
         return fn()
-    if getattr(owner, "_c2m_conv_bf16x3", False) or not _split16_now() or bf16_autocast():
+    # (under bf16 autocast the convolutions run the bf16 flavour and never touch the flag; the DCNv2 forwards -- fp32 under
+    # autocast, as the reference's custom_fwd(cast_inputs=float32) makes them -- still run f16 x 2 and do)
+    if getattr(owner, "_c2m_conv_bf16x3", False) or not _split16_now():
         if getattr(owner, "_c2m_conv_bf16x3", False):
             with conv_flavour("bf16x3"):
                 return fn()
@@ -1068,7 +1070,7 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     if tuple(offset.shape) != (B, 2 * dg * 9, H, W) or tuple(mask.shape) != (B, dg * 9, H, W):
         raise _lib.C2MError("offset/mask shape does not match [B, 2*dg*9, H, W] / [B, dg*9, H, W]")
     if algo is None:
-        f16 = _DCN_F16X2 and _SPLIT != "0" and _split16_now() and not bf16_autocast() and dcn_f16x2_ok(weight, dg)
+        f16 = _DCN_F16X2 and _SPLIT != "0" and _split16_now() and dcn_f16x2_ok(weight, dg)
     elif algo in ("fp32", "f16x2"):
         f16 = algo == "f16x2"
     else:

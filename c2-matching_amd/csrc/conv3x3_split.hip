@@ -838,6 +838,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+                if constexpr ((ABL & 512) != 0) {
+                  // (ablation: the ADDRESS pattern of quad-transposed stores -- lanes 4q .. 4q+3 write the four consecutive 16-byte
+                  // pieces of pixel 4q + qd -- with untransposed data: what would coalesced 64-byte runs per quad buy?)
+                  const int xq = x0 + 4 * (j >> 2) + qd, cq = cb * MW + mt * 32 + 4 * (4 * hi + (j & 3));
+                  if (xq < p.W && cq + 3 < p.Cout) {
+                    const size_t oq = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)xq * p.out_pix_pitch + cq;
+                    if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + oq);
+                    if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + oq);
+                    *reinterpret_cast<f32x4*>(p.out + oq) = v;
+                  }
+                  continue;
+                }
                 if constexpr (FL == 1) {
                   // bf16 flavour: the output / the residuals may hold bf16 (Params::io_flags; Cout % 4 == 0 then) -- the sum
                   // is taken in fp32 and rounded once
@@ -1028,6 +1040,7 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
         case 111: go(&split::conv3x3_split_kernel<NP, 2, 0, 111>, done_abl[11]); break;
         case 112: go(&split::conv3x3_split_kernel<NP, 2, 0, 112>, done_abl[12]); break;
         case 256: go(&split::conv3x3_split_kernel<NP, 2, 0, 256>, done_abl[0]); break;
+        case 512: { static unsigned long long d512 = 0; go(&split::conv3x3_split_kernel<NP, 2, 0, 512>, d512); break; }
         default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL mask\n"); return C2M_ERR_INVALID_ARG;
       }
       return rc;

@@ -68,6 +68,10 @@ PY
                 C2M_DCN_F16X2=0 timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_dcn16_off.log 2>&1 ;;
     dcn_variants) (echo "== in-tree"; timeout 300 python scripts/bench_dcn_nhwc.py
                    for v in $DCN_VARIANTS; do echo "== $v"; C2M_LIB=$R/build_exp/libc2m_$v.so timeout 300 python scripts/bench_dcn_nhwc.py; done) 2>&1 | grep -v "^\[{" > $O/dcn_variants.log ;;
+    abl512)     for abl in 0 512 64; do
+                  echo "=== C2M_SPLIT_ABL=$abl" >> $O/abl512.txt
+                  C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only '64->64 @640' --iters 20 2>&1 | grep "^{'layer" >> $O/abl512.txt
+                done ;;
     test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;
