@@ -891,7 +891,22 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)(2 * y) * p.out_row_pitch +
                         (size_t)(2 * x) * p.out_pix_pitch + (co_lane >> 2);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+              if (cb * MW + mt * 32 + 32 <= p.Cout && p.out_vec4) {
+                // whole 32-channel tile: lanes j / j + 32 hold output channels 8mt + 2qd + {0, 1} of the four output pixels;
+                // two v_permlane32_swap per output pixel hand lane j channels 8mt + 0..3 and lane j + 32 channels 8mt + 4..7:
+                // one 16-byte store each -- 8 stores per row instead of 32
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float q0 = acc[mt][nt][e], q1 = acc[mt][nt][4 + e], q2 = acc[mt][nt][8 + e], q3 = acc[mt][nt][12 + e];
+                  const auto ra = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q2), false, false);
+                  const auto rb = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q3), false, false);
+                  const unsigned a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+                  const f32x4 v = {__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1), __builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1)};
+                  *reinterpret_cast<f32x4*>(ob + (size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 3 * hi) = v;   // (ob holds + hi already: channel cb*16 + 8mt + 4hi)
+                }
+                continue;
+              }
 #pragma unroll
               for (int qd = 0; qd < 4; ++qd)
                 if (co_lane + mt * 32 + 8 * qd < p.Cout) {
@@ -899,6 +914,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                   for (int e = 0; e < 4; ++e)
                     ob[(size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 2 * qd] = acc[mt][nt][4 * qd + e];
                 }
+            }
           } else {
             const size_t HWs = (size_t)p.H * p.W;
             float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;

@@ -391,6 +391,13 @@ def test_conv3x3_split_output_modes(ops, dev, algo):
     want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double(), padding=1), 2), 0.1)
     assert tuple(got.shape) == (2, 64, 48, 80)
     assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    # ragged: 80 = 64 + 16 output channels (the lane-swapped 16-byte stores serve whole 32-channel tiles only), odd map
+    xr = _cl(_rand((1, 32, 9, 37), dev, 313))
+    wr_, br_ = _rand((80, 32, 3, 3), dev, 314, 0.05), _rand((80,), dev, 315)
+    got = ops.conv3x3(xr, wr_, br_, act=ops.ACT_LRELU, slope=0.1, out_mode="pixel_shuffle", algo=algo)
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(xr.double(), wr_.double(), br_.double(), padding=1), 2), 0.1)
+    assert tuple(got.shape) == (1, 20, 18, 74)
+    assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     w3, b3 = _rand((3, 64, 3, 3), dev, 307, 0.05), _rand((3,), dev, 308)
     got = ops.conv3x3(x, w3, b3, out_mode="nchw", algo=algo)
     want = F.conv2d(x.double(), w3.double(), b3.double(), padding=1)
