@@ -72,6 +72,10 @@ PY
                   echo "=== C2M_SPLIT_ABL=$abl" >> $O/abl512.txt
                   C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only '64->64 @640' --iters 20 2>&1 | grep "^{'layer" >> $O/abl512.txt
                 done ;;
+    tpw_sweep)  for t in 0 1 2 3 4 5 6 7 9 13; do
+                  echo "=== C2M_CONV_TPW=$t (0 = heuristic)" >> $O/tpw_sweep.txt
+                  C2M_CONV_TPW=$t timeout 200 python scripts/bench_conv.py --only "${TPW_ONLY:-64->64 @320}" --iters 20 2>&1 | grep "^{'layer" >> $O/tpw_sweep.txt
+                done ;;
     test_bf16)  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -rA -k "bf16" 2>&1 | tail -80 > $O/pytest_bf16.log ;;
     bench_conv) timeout 300 python scripts/bench_conv.py > $O/bench_conv.log 2>&1 ;;
     bench_dcn)  timeout 600 python scripts/bench_dcn.py > $O/bench_dcn.log 2>&1 ;;
