@@ -917,6 +917,23 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             }
           } else {
             const size_t HWs = (size_t)p.H * p.W;
+            if ((p.W & 3) == 0) {
+              // planar output, W % 4 == 0: the quad transpose of the DCN head (conv3x3_shared.h) -- lane 4q + i stores channel
+              // co + i of pixels 4q .. 4q + 3 as one 16-byte piece: 16 stores per wave and tile instead of 64.  (A quad's
+              // pixels are valid together, so the lanes the `continue` above removed never exchange with active ones.)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                  f32x4 v;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+                  const f32x4 t = quad_transpose(v, j);
+                  const int ch = co_lane + mt * 32 + 8 * qd + (j & 3);
+                  if (ch < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.Cout + ch) * HWs + (size_t)y * p.W + (x & ~3)) = t;
+                }
+              continue;
+            }
             float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)

@@ -402,6 +402,13 @@ def test_conv3x3_split_output_modes(ops, dev, algo):
     got = ops.conv3x3(x, w3, b3, out_mode="nchw", algo=algo)
     want = F.conv2d(x.double(), w3.double(), b3.double(), padding=1)
     assert got.is_contiguous() and float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    # planar output of many channels: W % 4 == 0 takes the quad-transposed 16-byte stores, W % 4 != 0 the dword stores
+    for (Co, H, W) in ((72, 11, 36), (72, 11, 38), (256, 9, 64)):
+        xn = _cl(_rand((2, 32, H, W), dev, 316))
+        wn, bn = _rand((Co, 32, 3, 3), dev, 317, 0.05), _rand((Co,), dev, 318)
+        got = ops.conv3x3(xn, wn, bn, act=ops.ACT_RELU, out_mode="nchw", algo=algo)
+        want = F.conv2d(xn.double(), wn.double(), bn.double(), padding=1).relu()
+        assert got.is_contiguous() and float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max()), (Co, H, W)
     for (B, C, Co, H, W) in ((2, 64, 64, 12, 64), (1, 128, 128, 22, 90), (1, 64, 32, 8, 6)):
         xp = _cl(_rand((B, C, H, W), dev, 310))
         wp, bp = _rand((Co, C, 3, 3), dev, 311, 1.0 / np.sqrt(9 * C)), _rand((Co,), dev, 312)
