@@ -152,6 +152,29 @@ def test_bench_flop_model_matches_kernel_tiling():
     assert bench.corr_executed_flops(B, C, h) == want == 9286793035776
 
 
+def test_bench_dcn_roofline_prices_both_gemm_arithmetics():
+    """bench.py's DCNv2 rows: the fp32 GEMM executes the algorithmic flops on the fp32 matrix pipe; the f16 x 2 GEMM executes
+    three products per k step on the f16 pipe -- `frac` is always executed / that pipe's dense peak, and `frac_vs_fp32_pipe`
+    keeps the figure north_star's DCNv2 bar was written for (algorithmic / 157.3 TF)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, C, H, ms = 16, 64, 640, 4.9
+    flops = B * 2.0 * C * 9 * C * H * H                       # SURVEY.md 8d
+    a = bench.dcn_roofline("large", B, C, C, H, ms, 20)
+    b = bench.dcn_roofline("large", B, C, C, H, ms, 20, f16x2=True)
+    assert a["algorithmic_flops_per_launch"] == b["algorithmic_flops_per_launch"] == flops
+    assert a["executed_flops_per_launch"] == flops and b["executed_flops_per_launch"] == 3 * flops
+    assert a["peak"] == bench.FP32_MATRIX_PEAK_TFLOPS and b["peak"] == bench.BF16_MATRIX_PEAK_TFLOPS
+    tf = flops / (ms * 1e-3) / 1e12
+    assert abs(a["frac"] - tf / 157.3) < 1e-3 and abs(b["frac"] - 3 * tf / 2500.0) < 1e-3
+    assert a["frac_vs_fp32_pipe"] == b["frac_vs_fp32_pipe"] and abs(b["frac_vs_fp32_pipe"] - tf / 157.3) < 1e-3
+    assert 0.0 < b["frac"] < 1.0
+
+
 def test_dcn_modules_are_copyable_and_picklable():
     """the deferred offset-mean watch must not make copy.deepcopy(net) / torch.save(net) fail."""
     import copy
