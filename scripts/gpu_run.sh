@@ -18,6 +18,7 @@ for stage in "$@"; do
     test_all)   timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | tail -220 > $O/pytest_gpu.log ;;
     diag_corr)  timeout 600 python scripts/diag_corr_filter.py --lr320 > $O/diag_corr_filter.log 2>&1 ;;
     bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; echo "rc=$?" >> $O/bench_default.log ;;
+    bench_dist1) C2M_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $O/bench_dist1.log 2>&1; echo "rc=$?" >> $O/bench_dist1.log ;;
     bench_quick) timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_quick.log 2>&1; echo "rc=$?" >> $O/bench_quick.log ;;
     bench_corr) timeout 300 python bench.py --workload corr --steps 10 --warmup 3 > $O/bench_corr.log 2>&1 ;;
     bench_train) timeout 300 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.log 2>&1
