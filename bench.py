@@ -235,7 +235,8 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, sr_gpu, idx_gpu, one_thread=
     correlation algorithm ref_map_util.py:26-86, oracle pre-offsets and oracle DCNv2 -- the reference has no CPU DCNv2).
     Warm-up run + three timed runs (median), each on a different pair of the timed batch (first, middle, last) so that the
     parity of the GPU forward is checked on three pairs: index map vs the CPU chain's own, SR vs the CPU chain run with ITS OWN
-    index map (unconditional) and, for pair 0, with the GPU's index map (isolates the decoder from near-tie flips)."""
+    index map (unconditional) and -- for every sampled pair, outside the timed part -- with the GPU's index map (isolates the
+    decoder from near-tie flips: `sr_max_abs_diff_given_gpu_index_map`; a second decoder pass only where the maps differ)."""
     import torch
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import cpu_chain
@@ -247,15 +248,13 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, sr_gpu, idx_gpu, one_thread=
     B = lq.shape[0]
     pairs = sorted({0, B // 2, B - 1})
 
-    def run(b, idx_for_offsets=None):
+    def run(b, cond=True):
         tm = {}
-        t0 = time.perf_counter()
         sr, idx, feats = cpu_chain.full_forward_cpu(ext, mp, net, lq[b:b + 1], up[b:b + 1], ref[b:b + 1], True, tm,
-                                                    idx_for_offsets=idx_for_offsets)
-        return time.perf_counter() - t0, tm, sr, idx, feats
+                                                    cond_idx=idx_gpu[b:b + 1] if cond else None)
+        return sum(tm.values()), tm, sr, idx, feats   # (the timed part: extractor + correspondence + restoration)
 
-    # warm-up (page in, thread pools); doubles as the "given the GPU's index map" parity run of pair 0
-    _, _, sr_cond, _, _ = run(0, idx_for_offsets=idx_gpu[0:1])
+    run(0, cond=False)   # warm-up (page in, thread pools)
     times, stage, parity = [], [], []
     for b in pairs:
         dt, tm, sr_cpu, idx_cpu, feats = run(b)
@@ -266,15 +265,15 @@ def cpu_baseline_restore(ext, mp, net, lq, up, ref, sr_gpu, idx_gpu, one_thread=
         parity.append({"pair": b, "index_map_flips": len(mg), "of_queries": int(idx_gpu[b].size),
                        "max_fp64_margin_of_flips": float(f"{max((abs(m[3]) for m in mg), default=0.0):.3g}"),
                        "sr_max_abs_diff": float(f"{float(d.max()):.3g}"), "sr_pixels_over_1e-3": int((d > 1e-3).sum()),
-                       "sr_pixels": int(d.numel())})
+                       "sr_pixels": int(d.numel()),
+                       "sr_max_abs_diff_given_gpu_index_map": float(f"{float((sr_gpu[b].cpu() - feats['sr_given_idx'][0]).abs().max()):.3g}")})
     med = sorted(times)[len(times) // 2]
     out = {"value": _rnd(1.0 / med, 4), "unit": "pairs/s", "cores": threads, "kind": "port",
            "cpu_model": model, "physical_cores": phys,
            "sample": f"pairs {pairs} of the step's {B}, whole forward each (PyTorch-CPU + C oracle), after a warm-up run; median of "
                      f"{', '.join(f'{t:.1f}' for t in times)} s",
            "stage_s": {k: _rnd(v, 2) for k, v in stage[times.index(med)].items()},
-           "parity_gpu_vs_cpu": parity,   # index maps at the IMAGE boundary (two conv implementations): profiles/bench_notes.md
-           "sr_max_abs_diff_given_gpu_index_map_pair0": float(f"{float((sr_gpu[0].cpu() - sr_cond[0]).abs().max()):.3g}")}
+           "parity_gpu_vs_cpu": parity}   # index maps at the IMAGE boundary (two conv implementations): profiles/bench_notes.md
     if one_thread:
         out["one_thread"] = cpu_one_thread(ext, mp, net, lq, up, ref)
     return out
@@ -372,6 +371,10 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra passes on the other convolution arithmetics")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="bf16: inference under torch.autocast(bfloat16) (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launch-path check without a GPU workload: respawn under torch.distributed.run, read RANK / LOCAL_RANK / "
+                         "WORLD_SIZE, init the process group ($C2M_BENCH_BACKEND, default nccl = RCCL; gloo on a CPU-only host), "
+                         "barrier + the MAX all-reduce the timing uses, print one JSON line, exit (tests/test_data_path.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -383,9 +386,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("C2M_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only with --plumbing-only
+    on_gpu = not (args.plumbing_only and backend == "gloo")
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     dist = None
     if world > 1 or os.environ.get("C2M_BENCH_FORCE_DIST") == "1":   # (the env var: exercise the RCCL path on a 1-GPU box)
         import torch.distributed as dist
@@ -394,8 +400,24 @@ def main():
                 os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
                 os.environ.setdefault("RANK", "0")
                 os.environ.setdefault("WORLD_SIZE", "1")
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            if on_gpu:
+                dist.init_process_group(backend, device_id=dev)  # RCCL over xGMI
+            else:
+                dist.init_process_group(backend)
     rccl_world = dist.get_world_size() if dist is not None else None
+    if args.plumbing_only:
+        # what every timed region does around its steps: barrier, then MAX over ranks of the per-rank time
+        t = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"plumbing": "ok", "backend": backend, "n_gpus": args.gpus, "world_size": world,
+                              "process_group_world": rccl_world, "max_over_ranks": float(t.item()),
+                              "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import c2m_amd
     ops = c2m_amd.ops

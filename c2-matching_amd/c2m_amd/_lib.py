@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ($C2M_LIB: another build of the same library -- kernel A/B measurements; the product path is the in-tree build)
 LIB_PATH = os.environ.get("C2M_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libc2m_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _lib = None

@@ -131,7 +131,7 @@ def last_corr_filter_tables():
 
 class corr_filter_mode:
     """`with ops.corr_filter_mode(0): ...` -- exact fp32 sweep only; (1): pre-filter + exact re-score (default); results are
-    identical (c2m_feature_match_set_filter).  Process-wide switch: measurement / tests, not for concurrent callers."""
+    identical (c2m_feature_match_set_filter).  Per calling thread (thread_local in the library): measurement / tests."""
 
     def __init__(self, mode):
         self.mode = int(mode)
@@ -147,7 +147,7 @@ class corr_filter_mode:
 
 class head_store_mode:
     """`with ops.head_store_mode(0): ...` -- the DCN head epilogue's dword planar stores; (1): 16-byte stores through the quad
-    transpose + flow window (default where W % 4 == 0); identical results (c2m_conv3x3_set_head_stores).  Process-wide."""
+    transpose + flow window (default where W % 4 == 0); identical results (c2m_conv3x3_set_head_stores).  Per calling thread."""
 
     def __init__(self, mode):
         self.mode = int(mode)
@@ -515,6 +515,12 @@ _range_lock = _threading.Lock()
 
 
 def _range_flag(dev):
+    """The int32 device flag f16 x 2 launches report into: the enclosing f16_range_guard's OWN flag (one per guard invocation,
+    so that concurrent guards on other threads / streams of the device cannot zero each other's report), else -- explicit
+    algo="split16" / "f16x2" calls outside any guard -- one per device, which the caller may read with range_flag_set()."""
+    g = getattr(_tls, "guard_flag", None)
+    if g is not None and g.device == (dev if dev.index is not None else torch.device(dev.type, torch.cuda.current_device())):
+        return g
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     t = _range_flags.get(key)
     if t is None:
@@ -529,6 +535,27 @@ def _split16_now():
     """f16 x 2 (True) or bf16 x 3 (False) for an fp32 split-kernel call of this thread right now."""
     ov = getattr(_tls, "flavour", None)
     return _SPLIT16 if ov is None else ov
+
+
+def _f16x2_auto():
+    """What algo=None resolves to in conv3x3 / conv3x3_dcn_head / dcn_v2_forward_nhwc: the f16 x 2 arithmetic only where
+    somebody reads the range flag afterwards -- inside an f16_range_guard (the fused module forwards) -- or where the caller
+    asked for it by name (`with ops.conv_flavour("f16x2")`, then the flag is the caller's to read: range_flag_set()).  A bare
+    direct call gets the full-range arithmetic (bf16 x 3 convolutions, fp32-MFMA DCNv2): never a silent NaN."""
+    ov = getattr(_tls, "flavour", None)
+    if ov is not None:
+        return ov
+    return _SPLIT16 and getattr(_tls, "guarded", False)
+
+
+def range_flag_set(device, clear=True):
+    """True if an f16 x 2 launch outside any guard reported an out-of-domain activation on `device` since the last clear (one
+    4-byte read-back)."""
+    f = _range_flag(device)
+    v = int(f.item()) != 0
+    if clear and v:
+        f.zero_()
+    return v
 
 
 class conv_flavour:
@@ -566,13 +593,12 @@ def f16_range_guard(owner, fn, device):
         # the range check reads a flag back, which a hipGraph capture cannot do: captured forwards run the full-range flavour
         with conv_flavour("bf16x3"):
             return fn()
-    flag = _range_flag(device)
-    flag.zero_()
-    _tls.guarded = True
+    flag = torch.zeros(1, dtype=torch.int32, device=device)   # this invocation's own flag (see _range_flag)
+    _tls.guarded, _tls.guard_flag = True, flag
     try:
         out = fn()
     finally:
-        _tls.guarded = False
+        _tls.guarded, _tls.guard_flag = False, None
     if int(flag.item()) == 0:
         return out
     import warnings
@@ -611,7 +637,7 @@ def _split_ok(srcs, weight, fast):
 
 
 def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=None, out_mode="nhwc", out=None, algo=None,
-            out2_grouped8=None, fast=False, out_dtype=None):
+            out2_grouped8=None, fast=False, out_dtype=None, dword_stores=False):
     """out = act(conv3x3(cat(srcs, dim=1)) + bias) + res1 + res2 on channels-last tensors, one kernel.
 
     bf16 tensors ("bf16" kernel and "nhwc" mode only -- what a bf16-autocast forward keeps its activations in between fused
@@ -628,7 +654,11 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     pieces per operand, six MFMAs per product sum, csrc/conv3x3_split.hip), "split16" (fp32-accurate on the f16 matrix pipe:
     two round-to-nearest f16 pieces per activation, per-tensor-scaled weights, THREE MFMAs per product sum; |x| < 65520),
     "bf16" (one rounded piece: a bf16 convolution with fp32 accumulation).  Auto: the split kernel wherever it applies (any
-    map size / mode, channels % 16 == 0), f16 x 2 flavour unless $C2M_CONV_SPLIT16=0.
+    map size / mode, channels % 16 == 0) -- its f16 x 2 flavour inside an f16_range_guard (the fused module forwards) or under
+    `ops.conv_flavour("f16x2")`, unless $C2M_CONV_SPLIT16=0; a bare direct call gets bf16 x 3 (full range: _f16x2_auto).
+    dword_stores: split kernels, "pixel_shuffle" / "nchw" modes: this call's epilogue stores one dword per lane instead of
+    the 16-byte lane-swapped / quad-transposed pieces (c2m_hip.h C2M_IO_DWORD_STORES: same bits, the other instruction
+    sequence -- tests and measurement; per call, nothing process-wide).
     $C2M_CONV_SPLIT=1 restricts it to calls with fast=True (the decoder; the extractor towers that feed the index search
     then stay on the fp32-MFMA kernels), $C2M_CONV_SPLIT=0 restores the round-2 choice everywhere: Winograd F(4,3) with
     fast=True / F(2,3) where the shapes allow, else direct."""
@@ -641,7 +671,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         reduced = bf16_autocast()
         if (out2_grouped8 is None and (_split_ok(srcs, weight, fast) or (reduced and _split_ok(srcs, weight, True))) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
                 and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
-            wino = 4 if reduced else 6 if _split16_now() else 3
+            wino = 4 if reduced else 6 if _f16x2_auto() else 3
         else:
             wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
@@ -672,6 +702,10 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
             io |= bit
     if io and (wino != 4 or out_mode != "nhwc"):
         raise _lib.C2MError("conv3x3: bfloat16 tensors need the bf16 kernel (algo='bf16' / bf16 autocast) in nhwc mode")
+    if dword_stores:
+        if io or wino not in (3, 4, 6) or out_mode not in ("pixel_shuffle", "nchw"):
+            raise _lib.C2MError("conv3x3: dword_stores selects a store path of the split kernels' pixel_shuffle / nchw epilogues")
+        io = 16
     d.io_flags = io
     d.wr = wr.data_ptr()
     if bias is not None:
@@ -915,7 +949,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
     slices = [(0, Cout)] if (split == 0 or Cout - split > 32 or split == Cout) else [(0, split), (split, Cout)]
     use_split = algo in ("split", "bf16", "split16") or (algo is None and _SPLIT != "0" and all(s_.shape[1] % 16 == 0 for s_ in srcs))
     split_id = (4 if (algo == "bf16" or (algo is None and bf16_autocast())) else
-                6 if (algo == "split16" or (algo is None and _split16_now())) else 3)
+                6 if (algo == "split16" or (algo is None and _f16x2_auto())) else 3)
     fam = []
     for (c0, c1) in slices:
         # split-bf16 kernel (any shape); else 64-channel-tileable slices on whole 32-pixel tiles take the Winograd F(2,3)
@@ -1038,7 +1072,7 @@ def refresh_weight_caches(module_or_params=None, all_kinds=False):
         ids = {id(p) for p in params}
     kinds = None
     if not all_kinds and not torch.is_grad_enabled():
-        kinds = {0, 1, 2, 4 if bf16_autocast() else 6 if _split16_now() else 3}
+        kinds = {0, 1, 2, 4 if bf16_autocast() else 6 if _f16x2_auto() else 3}
     return _wcache.refresh(ids, kinds) + _dcn_wcache.refresh(ids)
 
 
@@ -1059,8 +1093,9 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     -> channels_last [B,Co,H,W] (nhwc_out) or contiguous NCHW, with the activation applied.
     algo: "fp32" (implicit GEMM on the fp32 matrix pipe), "f16x2" (fp32 result on the f16 pipe, three products per k step:
     the convolutions' f16 x 2 arithmetic, domain |sample| < 65520 reported through the same range flag), None: f16 x 2
-    wherever the convolutions of this thread currently run it (ops.conv_flavour / f16_range_guard / $C2M_CONV_SPLIT16,
-    $C2M_DCN_F16X2=0 keeps fp32) and the geometry has that kernel."""
+    wherever the convolutions of this thread run it by default (_f16x2_auto: inside an f16_range_guard -- the fused module
+    forwards -- or under `ops.conv_flavour("f16x2")`; $C2M_DCN_F16X2=0 keeps fp32) and the geometry has that kernel; a bare
+    direct call runs fp32."""
     if not isinstance(inp_bordered, BorderedNHWC):
         raise _lib.C2MError("inp_bordered must be a BorderedNHWC")
     B, C, H, W = inp_bordered.B, inp_bordered.C, inp_bordered.H, inp_bordered.W
@@ -1070,7 +1105,7 @@ def dcn_v2_forward_nhwc(inp_bordered, weight, bias, offset, mask, deformable_gro
     if tuple(offset.shape) != (B, 2 * dg * 9, H, W) or tuple(mask.shape) != (B, dg * 9, H, W):
         raise _lib.C2MError("offset/mask shape does not match [B, 2*dg*9, H, W] / [B, dg*9, H, W]")
     if algo is None:
-        f16 = _DCN_F16X2 and _SPLIT != "0" and _split16_now() and dcn_f16x2_ok(weight, dg)
+        f16 = _DCN_F16X2 and _SPLIT != "0" and _f16x2_auto() and dcn_f16x2_ok(weight, dg)
     elif algo in ("fp32", "f16x2"):
         f16 = algo == "f16x2"
     else:

@@ -1566,7 +1566,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   p.out2_img_pitch = d->out2_img_pitch;
   p.range_flag = d->range_flag;
   p.io_flags = d->io_flags;
-  if (d->io_flags != 0) {
+  if (d->io_flags & C2M_IO_DWORD_STORES) {   // per-call reference store path of the split kernels' PixelShuffle / planar epilogues
+    if (!splitk || (d->out_mode != 1 && d->out_mode != 2) || (d->io_flags & ~C2M_IO_DWORD_STORES)) return C2M_ERR_UNSUPPORTED;
+  } else if (d->io_flags != 0) {
     if (d->algo != C2M_CONV_BF16 || d->out_mode != 0 || (d->io_flags & ~15)) return C2M_ERR_UNSUPPORTED;
     if ((d->io_flags & C2M_IO_SRC_BF16) && (d->nsrc != 1 || d->src[0].pix_pitch % 8 != 0 || d->src[0].row_pitch % 8 != 0 || d->src[0].img_pitch % 8 != 0))
       return C2M_ERR_UNSUPPORTED;   // 16-byte pieces of 8 bf16

@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                         (size_t)(2 * x) * p.out_pix_pitch + (co_lane >> 2);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              if (cb * MW + mt * 32 + 32 <= p.Cout && p.out_vec4) {
+              if (cb * MW + mt * 32 + 32 <= p.Cout && p.out_vec4 && !(p.io_flags & C2M_IO_DWORD_STORES)) {
                 // whole 32-channel tile: lanes j / j + 32 hold output channels 8mt + 2qd + {0, 1} of the four output pixels;
                 // two v_permlane32_swap per output pixel hand lane j channels 8mt + 0..3 and lane j + 32 channels 8mt + 4..7:
                 // one 16-byte store each -- 8 stores per row instead of 32
@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             }
           } else {
             const size_t HWs = (size_t)p.H * p.W;
-            if ((p.W & 3) == 0) {
+            if ((p.W & 3) == 0 && !(p.io_flags & C2M_IO_DWORD_STORES)) {
               // planar output, W % 4 == 0: the quad transpose of the DCN head (conv3x3_shared.h) -- lane 4q + i stores channel
               // co + i of pixels 4q .. 4q + 3 as one 16-byte piece: 16 stores per wave and tile instead of 64.  (A quad's
               // pixels are valid together, so the lanes the `continue` above removed never exchange with active ones.)
@@ -1004,7 +1004,7 @@ int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long 
   return check_launch();
 }
 
-int g_head_stores = -1;   // c2m_conv3x3_set_head_stores
+thread_local int g_head_stores = -1;   // c2m_conv3x3_set_head_stores
 
 template <int NP, int MT>
 static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {

@@ -573,7 +573,7 @@ int launch_corr_mfma(hipStream_t st, const float* fin, const float* fref, int B,
 }  // namespace
 
 namespace {
-int g_filter_mode = -1;   // -1: $C2M_CORR_FILTER (default on), 0 / 1: forced by c2m_feature_match_set_filter
+thread_local int g_filter_mode = -1;   // -1: $C2M_CORR_FILTER (default on), 0 / 1: forced by c2m_feature_match_set_filter
 }
 
 extern "C" int c2m_feature_match_set_filter(int mode) {

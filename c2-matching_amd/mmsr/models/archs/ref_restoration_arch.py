@@ -103,7 +103,7 @@ def _fused_body(body, f, skip=None):
     ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue.  fast=True: decoder
     convolutions may take the Winograd F(4,3) kernel (ops.conv3x3) where the map is a whole number of 64-pixel tiles wide."""
     n = len(body)
-    if _BF16_IO and _ops.bf16_autocast() and blk_bf16_ok(body):
+    if _BF16_IO and _ops._SPLIT != "0" and _ops.bf16_autocast() and blk_bf16_ok(body):   # (bf16 tensors need the split kernel's bf16 flavour)
         # bf16 autocast (BASELINE configs[4]): the residual stream and the block-internal tensor travel as bf16 -- half the
         # HBM bytes of these launches, the tile goes HBM -> LDS without passing registers (c2m_conv3x3_desc.io_flags).  Sums
         # (bias, residuals) are taken in fp32 inside the kernel; the body's result leaves as fp32.  (torch's own autocast

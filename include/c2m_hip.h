@@ -43,7 +43,7 @@ typedef enum c2m_status {
   C2M_ERR_NO_DEVICE = 5      /* no gfx950 device visible to the HIP runtime */
 } c2m_status;
 
-int c2m_abi_version(void);                 /* bumped on any signature change; currently 1 */
+int c2m_abi_version(void);                 /* bumped on any signature change; currently 2 */
 const char* c2m_status_string(int status); /* static string, never NULL */
 const char* c2m_last_hip_error(void);      /* hipGetErrorString of the last failing HIP call on this thread */
 int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
@@ -92,7 +92,8 @@ int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* 
  *                 chain and the first maximum taken (corr_filter.hip).  Needs is_norm, |x| < 3.99 everywhere and ref patch
  *                 norms >= 0.5 (channel-normalised features satisfy all three); anything else falls back to the exact
  *                 sweep on the device, without a host round trip.
- * mode: 1 pre-filter (default), 0 exact sweep only, -1 follow $C2M_CORR_FILTER (unset = 1).  Process-wide.
+ * mode: 1 pre-filter (default), 0 exact sweep only, -1 follow $C2M_CORR_FILTER (unset = 1).  Per CALLING THREAD (thread_local: a
+ * DataParallel replica thread or another stream's host thread never sees a test's setting); measurement and tests.
  */
 int c2m_feature_match_set_filter(int mode);
 
@@ -101,7 +102,7 @@ int c2m_feature_match_set_filter(int mode);
  *   1 (default, maps with W % 4 == 0)  16-byte planar stores after a 4 x 4 register transpose inside lane quads, pre-offsets
  *                                      from a per-row flow window held in registers (ds_bpermute look-ups);
  *   0                                  dword planar stores, one 8-byte flow load per (4 channels, pixel).
- * mode: 1 / 0, -1 follow $C2M_HEAD_QUAD (unset = 1).  Process-wide; measurement and tests.
+ * mode: 1 / 0, -1 follow $C2M_HEAD_QUAD (unset = 1).  Per CALLING THREAD (thread_local); measurement and tests.
  */
 int c2m_conv3x3_set_head_stores(int mode);
 
@@ -318,6 +319,9 @@ typedef struct c2m_conv3x3_desc {
 #define C2M_IO_OUT_BF16 2
 #define C2M_IO_RES1_BF16 4
 #define C2M_IO_RES2_BF16 8
+#define C2M_IO_DWORD_STORES 16   /* split algorithms, C2M_OUT_NHWC_PIXEL_SHUFFLE2 / C2M_OUT_NCHW only (alone): take the epilogue's
+                                    one-dword-per-lane stores instead of the 16-byte lane-swapped / quad-transposed ones -- the
+                                    same bits through the other instruction sequence; per call (tests, measurement) */
 
 size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout);   /* 0 if the geometry is unsupported (Cin % 32 != 0) */
 int c2m_conv3x3_relayout_f32(c2m_stream_t stream, const float* weight /* [Cout][Cin][3][3] */, int Cin, int Cout, float* wr);

@@ -88,26 +88,37 @@ def correspondence_cpu(feats1, feats2, use_conv_algorithm=True):
 
 
 @torch.no_grad()
-def full_forward_cpu(ext, mp, net_g, lq, up, ref, use_conv_algorithm=True, timings=None, idx_for_offsets=None):
+def _pre_offsets_of(idx_map, h, w):
+    offs = [oracle.build_pre_offsets(np.asarray(idx_map[b], dtype=np.int64), h, w) for b in range(len(idx_map))]
+    return {"relu3_1": torch.from_numpy(np.stack([o[0] for o in offs])),
+            "relu2_1": torch.from_numpy(np.stack([o[1] for o in offs])),
+            "relu1_1": torch.from_numpy(np.stack([o[2] for o in offs]))}
+
+
+@torch.no_grad()
+def full_forward_cpu(ext, mp, net_g, lq, up, ref, use_conv_algorithm=True, timings=None, idx_for_offsets=None, cond_idx=None):
     """-> (sr [B,3,4h,4w], max_idx, feats dict).  ext / mp / net_g are the (GPU or CPU) modules whose weights to use.
     idx_for_offsets: build the pre-offsets from this index map [B,h-2,w-2] instead of the CPU one (isolates the decoder
-    from fp32 near-tie flips between two convolution implementations of the extractor); the CPU map is still returned."""
+    from fp32 near-tie flips between two convolution implementations of the extractor); the CPU map is still returned.
+    cond_idx: AFTER the timed forward, also evaluate the decoder with the pre-offsets of this index map (only if it differs
+    from the CPU map -- otherwise the result is the same tensor) -> feats["sr_given_idx"]."""
     ext_c, mp_c, g_c = copy.deepcopy(ext).cpu().eval(), copy.deepcopy(mp).cpu().eval(), cpu_copy(net_g)
     lq, up, ref = lq.detach().float().cpu(), up.detach().float().cpu(), ref.detach().float().cpu()
     t0 = time.perf_counter()
     feats = ext_c(up, ref)
     t1 = time.perf_counter()
     idx, pre = correspondence_cpu(feats["dense_features1"], feats["dense_features2"], use_conv_algorithm)
+    h, w = feats["dense_features1"].shape[2:]
     if idx_for_offsets is not None:
-        h, w = feats["dense_features1"].shape[2:]
-        offs = [oracle.build_pre_offsets(np.asarray(idx_for_offsets[b], dtype=np.int64), h, w) for b in range(len(idx))]
-        pre = {"relu3_1": torch.from_numpy(np.stack([o[0] for o in offs])),
-               "relu2_1": torch.from_numpy(np.stack([o[1] for o in offs])),
-               "relu1_1": torch.from_numpy(np.stack([o[2] for o in offs]))}
+        pre = _pre_offsets_of(idx_for_offsets, h, w)
     ref_feat = mp_c.vgg(ref)
     t2 = time.perf_counter()
     sr = g_c(lq, pre, ref_feat)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update({"extractor_s": t1 - t0, "correspondence_s": t2 - t1, "restoration_s": t3 - t2})
+    if cond_idx is not None:
+        same = np.array_equal(np.asarray(cond_idx, dtype=np.int64), np.asarray(idx, dtype=np.int64))
+        feats = dict(feats)
+        feats["sr_given_idx"] = sr if same else g_c(lq, _pre_offsets_of(cond_idx, h, w), ref_feat)
     return sr, idx, feats

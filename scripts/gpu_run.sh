@@ -31,21 +31,6 @@ for stage in "$@"; do
                 timeout 300 python bench.py --lr 320 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_f32.log 2>&1 ;;
     bench_cfg5_bf16) timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16.log 2>&1
                 C2M_BF16_IO=0 timeout 300 python bench.py --lr 320 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_bf16_f32io.log 2>&1 ;;
-    dbg_bf16)   timeout 300 python scripts/debug/bf16io.py > $O/dbg_bf16.log 2>&1
-                timeout 600 python -m pytest tests/test_restoration_gpu.py -m gpu -q -x -k "full_chain_under_bf16" 2>&1 | tail -60 >> $O/dbg_bf16.log ;;
-    prof_cfg5)  cd /tmp
-                timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
-                cd $R
-                python - "$O" <<'PY'
-import csv, sys, glob, collections
-O = sys.argv[1]
-f = glob.glob(O + "/prof_cfg5/**/step_kernel_stats.csv", recursive=True)
-rows = list(csv.DictReader(open(f[0]))) if f else []
-with open(O + "/prof_cfg5_kernel_stats.txt", "w") as out:
-    for r in rows[:40]:
-        out.write("%-110s calls %6s total_ms %9.3f avg_us %9.2f pct %s\n" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
-PY
-                rm -rf $O/prof_cfg5 ;;
     bench_conv16) (echo "== bf16 kernel, fp32 tensors, B=4"; timeout 200 python scripts/bench_conv.py --batch 4 --algo bf16 --only body
                    echo "== bf16 kernel, bf16 tensors, B=4"; timeout 200 python scripts/bench_conv.py --batch 4 --io16 --only body) > $O/bench_conv16.log 2>&1 ;;
     abl16)      for abl in 0 1 2 8 16 32 64 43 48 107; do

@@ -325,7 +325,12 @@ def test_conv3x3_split_matches_fp64_conv2d(ops, dev, case, algo):
     scale = max(1.0, float(want.abs().max()))
     err = float((got.double() - want).abs().max())
     assert err < 1e-5 * scale, err
-    if algo == ("split16" if ops._SPLIT16 else "split"):   # the automatic choice is this kernel
+    # the automatic choice: f16 x 2 where a range guard / an explicit flavour covers its domain, bf16 x 3 for a bare call
+    if algo == "split16" and ops._SPLIT16:
+        with ops.conv_flavour("f16x2"):
+            auto = ops.conv3x3(xs, w, b, fast=True, **kw)
+        assert torch.equal(auto, got)
+    elif algo == "split":
         auto = ops.conv3x3(xs, w, b, fast=True, **kw)
         assert torch.equal(auto, got)
 
@@ -564,6 +569,40 @@ def test_dcn_head_store_paths_are_bit_identical_at_full_size(ops, dev, algo):
     with ops.head_store_mode(1):
         r1 = ops.conv3x3_dcn_head([f2a, f2b], w2, b2, dg, flow, 2, None, algo=algo)
     assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+
+
+@pytest.mark.parametrize("algo", SPLIT_ALGOS)
+def test_pixel_shuffle_and_planar_store_paths_are_bit_identical_at_full_size(ops, dev, algo):
+    """the PixelShuffle epilogue's lane-swapped 16-byte stores and the planar (NCHW) epilogue's
+    quad-transposed 16-byte stores against their one-dword-per-lane paths (conv3x3(dword_stores=True), per call) on
+    chip-filling launches -- configs[2]'s own shapes at B=16: tail 64 -> 256 PixelShuffle @320^2 (105 M values per call,
+    6 400 tiles on 512 resident workgroup slots: two workgroups per CU throughout) and the extractor's planar 256-channel
+    output @160^2 plus a 64-channel planar map @640^2 -- repeated, both flavours: every bit equal.  (The staged stores
+    withdrawn in round 4 were wrong once in 10^6 values and only on full CUs; small maps cannot see that class.)"""
+    x = _cl(_rand((16, 64, 320, 320), dev, 390))
+    w, b = _rand((256, 64, 3, 3), dev, 391, 0.05), _rand((256,), dev, 392)
+    kw = dict(act=ops.ACT_LRELU, slope=0.1, out_mode="pixel_shuffle", algo=algo)
+    ref = ops.conv3x3(x, w, b, dword_stores=True, **kw)
+    assert tuple(ref.shape) == (16, 64, 640, 640) and bool(torch.isfinite(ref).all())
+    for rep in range(3):
+        got = ops.conv3x3(x, w, b, **kw)
+        assert torch.equal(got, ref), ("pixel_shuffle", rep)
+        del got
+    del ref, x
+    for (B, C, Co, H, W, seed) in ((16, 64, 256, 160, 160, 393), (16, 32, 64, 640, 640, 396)):
+        xn = _cl(_rand((B, C, H, W), dev, seed))
+        wn, bn = _rand((Co, C, 3, 3), dev, seed + 1, 0.05), _rand((Co,), dev, seed + 2)
+        kw = dict(act=ops.ACT_RELU, out_mode="nchw", algo=algo)
+        ref = ops.conv3x3(xn, wn, bn, dword_stores=True, **kw)
+        assert ref.is_contiguous() and bool(torch.isfinite(ref).all())
+        for rep in range(3):
+            got = ops.conv3x3(xn, wn, bn, **kw)
+            assert torch.equal(got, ref), ("nchw", Co, H, rep)
+            del got
+        # ... and the dword path itself is the convolution (a sub-block against float64)
+        want = F.conv2d(xn[:1, :, :40, :72].double(), wn.double(), bn.double(), padding=1).relu()[:, :, :38, :70]
+        assert float((ref[:1, :, :38, :70].double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+        del ref, xn
 
 
 def test_weight_cache_refresh_follows_data_writes(ops, dev):

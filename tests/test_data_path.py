@@ -114,3 +114,31 @@ def test_dist_iter_sampler_partitions_the_epoch_across_gloo_ranks(world):
     inter = [v for t in zip(*lists) for v in t]
     assert inter == slots                                                   # disjoint slices whose union is the epoch
     assert sorted(set(inter)) == list(range(37))                            # every sample is drawn
+
+
+def test_bench_gpus2_launch_path_reaches_the_process_group():
+    """`python bench.py --gpus 2` as the driver's plain command: bench.py re-executes itself under torch.distributed.run with
+    two ranks on 127.0.0.1, every rank reads RANK / LOCAL_RANK / WORLD_SIZE, joins the process group, passes the barrier and
+    the MAX all-reduce that the timing uses, rank 0 prints one JSON line (the first multi-GPU run must not
+    die on plumbing).  CPU host: the gloo backend stands in for RCCL ($C2M_BENCH_BACKEND), the device calls are skipped."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, C2M_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--plumbing-only"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout                  # rank 0 only
+    d = lines[0]
+    assert d["plumbing"] == "ok" and d["n_gpus"] == 2 and d["world_size"] == 2 and d["process_group_world"] == 2
+    assert d["max_over_ranks"] == 2.0 and d["master"] == "127.0.0.1"
+    # a mismatched launch is refused, not silently run on the wrong world size
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)

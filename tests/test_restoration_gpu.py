@@ -245,6 +245,56 @@ def test_convolution_arithmetics_agree_end_to_end(dev):
     assert bool(torch.isfinite(out["f16x2"]["sr_own"]).all())
 
 
+def _check_sample_against_oracle(oracle, g, feats, idx, pre, taps, b):
+    """sample b of a configs[2]-shaped batch against the oracle: index map on row slices (bit-exact), the pre-offset maps
+    of all three scales (bit-exact), the three DynAgg outputs at 160 / 320 / 640 (1e-4 * scale)"""
+    f1 = oracle.feature_normalize(feats["dense_features1"][b].cpu().numpy())
+    f2 = oracle.feature_normalize(feats["dense_features2"][b].cpu().numpy())
+    hidx = idx[b].cpu().numpy()
+    for rows in ((0, 3), (77, 80), (155, 158)):
+        oi, _ = oracle.feature_match_index(f1, f2, 3, 1, 1, True, True, qrows=rows)
+        assert np.array_equal(hidx[rows[0]:rows[1]], oi[rows[0]:rows[1]])
+    o3, o2, o1 = oracle.build_pre_offsets(hidx, 160, 160)
+    assert np.array_equal(pre["relu3_1"][b].cpu().numpy(), o3)
+    assert np.array_equal(pre["relu2_1"][b].cpu().numpy(), o2)
+    assert np.array_equal(pre["relu1_1"][b].cpu().numpy(), o1)
+    for stage, key in (("small", "relu3_1"), ("medium", "relu2_1"), ("large", "relu1_1")):
+        t = taps[stage]
+        mod = getattr(g.dyn_agg_restore, f"{stage}_dyn_agg")
+        want, _, _ = _dynagg_expected(oracle, mod, t["ref"], t["feat"], pre[key], b)
+        if t["lrelu"] is not None:
+            want = np.where(want > 0, want, want * np.float32(t["lrelu"]))
+        got = t["out"][b].cpu().numpy()
+        err = float(np.abs(got - want).max())
+        assert err < 1e-4 * max(1.0, float(np.abs(want).max())), f"DynAgg {stage} at LR 160, sample {b}: {err}"
+
+
+def test_cfg3_full_forward_at_batch16(dev):
+    """BASELINE configs[2] AT ITS STATED BATCH OF 16: the full restoration forward (extractor ->
+    correlation -> pre-offsets -> VGG taps -> RestorationNet, fused path, default arithmetic) on 16 pairs of LR 160x160 /
+    Ref 500x500 (padded to 640x640); the LAST sample (15: the far end of every batch stride) is checked against the
+    oracle -- index-map row slices and pre-offsets bit-exact, the three DynAgg outputs within 1e-4 * scale -- and its SR
+    image equals the one the same pair gives in a batch of one (north_star's 1e-3)."""
+    import c2m_oracle as oracle
+    ext, mp, g = _build_chain(dev)
+    lq, up, ref = _synthetic_pairs(16, 160, dev, 4100)
+    taps = {}
+    _hook_dynagg(g, taps)
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        assert g._use_fused(lq, pre, ref_feat)
+        sr = g(lq, pre, ref_feat)
+        idx, _ = mp.match(feats)
+    assert tuple(sr.shape) == (16, 3, 640, 640) and bool(torch.isfinite(sr).all())
+    _check_sample_against_oracle(oracle, g, feats, idx, pre, taps, 15)
+    with torch.no_grad():
+        feats1 = ext(up[15:], ref[15:])
+        pre1, ref_feat1 = mp(feats1, ref[15:])
+        sr1 = g(lq[15:], pre1, ref_feat1)
+    assert float((sr1[0] - sr[15]).abs().max()) < 1e-3
+
+
 def test_cfg3_chain_160_batch2(dev):
     """BASELINE configs[2] shape at B=2: extractor -> correlation/index map -> pre-offsets -> VGG taps -> RestorationNet at
     LR 160x160 / Ref 500x500 padded to 640x640.  Sample 1 (not 0: batch indexing) is checked against the oracle: index
