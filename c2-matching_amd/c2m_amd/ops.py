@@ -354,7 +354,7 @@ class _WeightCache:
             self._d.clear()
             self._tables.clear()
 
-    _SPLIT_PIECES = {3: 3, 4: 1, 5: 3, 6: 2}     # cache kind -> pieces of the split-kernel image
+    _SPLIT_PIECES = {3: 3, 4: 1, 5: 3, 6: 2, 7: 0x42, 8: 0x22}     # cache kind -> pieces code of the split-kernel image (7 / 8: Winograd F(4,3) / F(2,3) along y on f16 x 2)
 
     def refresh(self, param_ids=None, kinds=None):
         with self._lock:
@@ -382,7 +382,7 @@ class _WeightCache:
                 Co, Ci = (rows[1] - rows[0] if rows is not None else w.shape[0]), w.shape[1]
                 cin_k, cout_k = (Co, Ci) if kind == 5 else (Ci, Co)      # the data-gradient conv swaps the roles
                 pieces = self._SPLIT_PIECES[kind]
-                nbytes = _lib.lib().c2m_conv3x3_relayout_split_bytes(cin_k, cout_k, pieces) - (256 if pieces == 2 else 0)
+                nbytes = _lib.lib().c2m_conv3x3_relayout_split_bytes(cin_k, cout_k, pieces) - (256 if (pieces & 15) == 2 else 0)
                 wptr = w.data_ptr() + (rows[0] * Ci * 9 * 4 if rows is not None else 0)
                 jobs.append((wptr, value.data_ptr(), cin_k, cout_k, pieces | ((1 if cout_k <= 32 else 2) << 8) | ((1 if kind == 5 else 0) << 16),
                              nbytes // 2))
@@ -403,7 +403,7 @@ class _WeightCache:
                     rowsl.append([wptr, iptr, ci, co, flags, elems, first, 0])
                     first += (elems + 255) // 256
                 host = torch.tensor(rowsl, dtype=torch.int64).pin_memory()
-                tab = (sig, host.to(dev, non_blocking=True), first, int(any((j[4] & 0xff) == 2 for j in jobs)), host)
+                tab = (sig, host.to(dev, non_blocking=True), first, int(any((j[4] & 0xf) == 2 for j in jobs)), host)
                 if len(self._tables) >= 64:      # (tables of parameter sets that no longer exist: a handful of KiB each)
                     self._tables.clear()
                 self._tables[tkey] = tab
@@ -426,8 +426,8 @@ class _WeightCache:
         w = w.contiguous()
         L = _lib.lib()
         wino = int(wino)
-        if wino in (3, 4, 5, 6):   # split images (3 exact bf16 pieces / 1 rounded piece per weight; 6: scaled f16 x 2); 5: of the data-gradient conv
-            pieces = 1 if wino == 4 else 2 if wino == 6 else 3
+        if wino in (3, 4, 5, 6, 7, 8):   # split images (3 exact bf16 pieces / 1 rounded piece per weight; 6: scaled f16 x 2; 7 / 8: its Winograd-along-y images); 5: of the data-gradient conv
+            pieces = 1 if wino == 4 else 2 if wino == 6 else 0x42 if wino == 7 else 0x22 if wino == 8 else 3
             nbytes = L.c2m_conv3x3_relayout_split_bytes(Co, Ci, pieces) if wino == 5 else L.c2m_conv3x3_relayout_split_bytes(Ci, Co, pieces)
         else:
             nbytes = (L.c2m_conv3x3_relayout_bytes, L.c2m_conv3x3_relayout_wino_bytes, L.c2m_conv3x3_relayout_wino4_bytes)[wino](Ci, Co)
@@ -440,7 +440,7 @@ class _WeightCache:
             if wino == 5:
                 _lib.check(L.c2m_conv3x3_relayout_split_dgrad_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
                            "c2m_conv3x3_relayout_split_dgrad_f32")
-            elif wino in (3, 4, 6):
+            elif wino in (3, 4, 6, 7, 8):
                 _lib.check(L.c2m_conv3x3_relayout_split_f32(_stream(), w.data_ptr(), Ci, Co, pieces, wr.data_ptr()),
                            "c2m_conv3x3_relayout_split_f32")
             else:
@@ -492,14 +492,18 @@ _SPLIT = _os.environ.get("C2M_CONV_SPLIT", "all")
 # domain |x| < 65520: include/c2m_hip.h C2M_CONV_SPLIT_F16X2); "0" -- the bf16 x 3 flavour (full fp32 range) everywhere.
 # The autograd path (conv3x3_autograd: gradients can be tiny) always runs bf16 x 3.
 _SPLIT16 = _os.environ.get("C2M_CONV_SPLIT16", "1") != "0"
+# C2M_CONV_WINO16: "43" (default) -- where the f16 x 2 flavour would run a channels-last layer with Cout % 64 == 0 it runs behind a
+# Winograd F(4,3) transform ALONG Y (csrc/conv3x3_wino16.hip: half the matrix instructions; same tolerances); "23": F(2,3); "0": off
+_WINO16 = {"43": 7, "23": 8}.get(_os.environ.get("C2M_CONV_WINO16", "43"), 0)
 # C2M_DCN_F16X2: "1" (default) -- the DCNv2 forward's implicit GEMM follows the convolutions onto the f16 x 2 arithmetic
 _DCN_F16X2 = _os.environ.get("C2M_DCN_F16X2", "1") != "0"
 # internal kernel ids (= weight-cache kinds; 5 is the data-gradient image of the bf16 x 3 kernel) -> c2m_conv3x3_desc.algo
-ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4, "split16": 6}
-_DESC_ALGO = (0, 1, 2, 3, 4, 3, 5)
-_FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16", "split_bf16x3", "split_f16x2")
-# matrix flops actually executed per algorithmic (direct-convolution) flop, and the pipe they run on
-_EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0, 6.0, 3.0)
+ALGO_IDS = {"direct": 0, "winograd": 1, "winograd4": 2, "split": 3, "bf16": 4, "split16": 6, "wino16": 7, "wino16_f23": 8}
+_DESC_ALGO = (0, 1, 2, 3, 4, 3, 5, 6, 7)
+_FAMILY = ("direct", "winograd_f23", "winograd_f43", "split_bf16x3", "bf16", "split_bf16x3", "split_f16x2", "wino16_f43y", "wino16_f23y")
+# matrix flops actually executed per algorithmic (direct-convolution) flop, and the pipe they run on (Winograd along y on
+# f16 x 2: three products x 6/12 (4/6) of the taps x 32/30 of the columns -- two MFMA columns of a tile are halo only)
+_EXEC_FACTOR = (1.0, 2.0 / 3.0, 0.5, 6.0, 1.0, 6.0, 3.0, 3.0 * 0.5 * 32.0 / 30.0, 3.0 * (2.0 / 3.0) * 32.0 / 30.0)
 
 
 # ---- f16 x 2 is the DEFAULT arithmetic of fp32 inference, and its domain is |activation| < 65520: outside it the kernel
@@ -672,6 +676,9 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
         if (out2_grouped8 is None and (_split_ok(srcs, weight, fast) or (reduced and _split_ok(srcs, weight, True))) and (out_mode != "nhwc_pool2" or (H % 2 == 0 and W % 2 == 0))
                 and (out_mode not in ("nhwc", "nhwc_pool2") or Cout % 4 == 0)):   # channels-last stores are 16-byte vectors
             wino = 4 if reduced else 6 if _f16x2_auto() else 3
+            if (wino == 6 and _WINO16 and out_mode == "nhwc" and Cout % 64 == 0 and out is None and out_dtype in (None, torch.float32)
+                    and all(t_ is None or t_.dtype == torch.float32 for t_ in (srcs[0], res1, res2))):
+                wino = _WINO16
         else:
             wino = 2 if (fast and _wino4_ok(srcs, weight, out_mode, W)) else 1 if _wino_ok(srcs, weight, out_mode, W) else 0
     else:
@@ -744,7 +751,7 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     else:
         raise _lib.C2MError(f"unknown out_mode {out_mode}")
     d.out = out.data_ptr()
-    if wino == 6:
+    if wino in (6, 7, 8):
         d.range_flag = _range_flag(dev).data_ptr()
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
@@ -1072,7 +1079,7 @@ def refresh_weight_caches(module_or_params=None, all_kinds=False):
         ids = {id(p) for p in params}
     kinds = None
     if not all_kinds and not torch.is_grad_enabled():
-        kinds = {0, 1, 2, 4 if bf16_autocast() else 6 if _f16x2_auto() else 3}
+        kinds = {0, 1, 2, 4} if bf16_autocast() else ({0, 1, 2, 6, 7, 8} if _f16x2_auto() else {0, 1, 2, 3})
     return _wcache.refresh(ids, kinds) + _dcn_wcache.refresh(ids)
 
 

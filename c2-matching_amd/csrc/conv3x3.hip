@@ -1394,6 +1394,7 @@ namespace conv {   // conv3x3_split.hip
 size_t split_relayout_bytes(int Cin, int Cout, int np);
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad);
 int launch_split(hipStream_t st, Params p, int np);
+int launch_wino16(hipStream_t st, Params p, int R);   // conv3x3_wino16.hip
 int set_head_stores(int mode);
 int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long long nblocks, int any_f16);
 }  // namespace conv
@@ -1509,7 +1510,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     return C2M_ERR_INVALID_ARG;
   const bool wino4 = d->algo == C2M_CONV_WINOGRAD_F43X;
   const bool wino = d->algo == C2M_CONV_WINOGRAD_F23X || wino4;   // both: 16-channel chunks, 64-cout blocks
-  const bool splitk = d->algo == C2M_CONV_SPLIT_BF16X3 || d->algo == C2M_CONV_BF16 || d->algo == C2M_CONV_SPLIT_F16X2;   // 16-channel chunks, any shape
+  const bool wino16 = d->algo == C2M_CONV_WINO_F16X2_F43Y || d->algo == C2M_CONV_WINO_F16X2_F23Y;   // conv3x3_wino16.hip
+  const bool splitk = d->algo == C2M_CONV_SPLIT_BF16X3 || d->algo == C2M_CONV_BF16 || d->algo == C2M_CONV_SPLIT_F16X2 || wino16;   // 16-channel chunks, any shape
+  if (wino16 && (d->out_mode != 0 || d->Cout % 64 != 0 || d->out2 || d->io_flags != 0)) return C2M_ERR_UNSUPPORTED;
   if (d->algo != 0 && !wino && !splitk) return C2M_ERR_INVALID_ARG;
   if (splitk && (d->out2 || (d->out_mode == 4 && (d->H % 2 != 0 || d->W % 2 != 0 || d->res1 || d->res2)))) return C2M_ERR_UNSUPPORTED;
   if (wino && ((d->out_mode != 0 && d->out_mode != 3 && d->out_mode != 4) || d->Cout % 64 != 0 || d->W % 32 != 0)) return C2M_ERR_UNSUPPORTED;
@@ -1588,6 +1591,10 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
     const long long ext = ((long long)(d->H - 1) * d->src[sidx].row_pitch + (long long)(d->W - 1) * d->src[sidx].pix_pitch +
                            d->src[sidx].C) * 4;
     if (ext >= 0x7fffffffLL || d->src[sidx].row_pitch < 0 || d->src[sidx].pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
+  }
+  if (wino16) {
+    ProfileScope prof(C2M_KERNEL_CONV3X3_SPLIT, as_stream(stream));
+    return conv::launch_wino16(as_stream(stream), p, d->algo == C2M_CONV_WINO_F16X2_F43Y ? 4 : 2);
   }
   if (splitk) {
     ProfileScope prof(C2M_KERNEL_CONV3X3_SPLIT, as_stream(stream));

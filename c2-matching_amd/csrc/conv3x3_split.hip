@@ -158,29 +158,60 @@ __device__ __forceinline__ unsigned short bf16_piece(float w, int pl, bool rne) 
 // fl = 2: the image is followed by a 256-byte tail of 32-bit slots: [0] float 1/S; uint bits of max |w|: [3] written by
 // weight_absmax_kernel (single-tensor path: zeroed + atomicMax), [8 .. 8 + ABSMAX_SPLIT) partial maxima of
 // weight_absmax_multi_kernel (each overwritten by its own workgroup: nothing to zero, no atomics)
-__device__ __forceinline__ void relayout_split_elem(const float* __restrict__ w, int Cin, int Cout, int fl, int MT, long long total,
+// fl = 2 | R << 4 (R = 4, 2): f16 x 2 images of the Winograd F(R,3)-along-y kernel (conv3x3_wino16.hip): the kernel-row index dy
+// becomes the transform position t = 0 .. R+1, value = piece of U_t[co][ci][dx] = sum_dy G[t][dy] w[co][ci][dy][dx] (float64,
+// rounded once), G = 4 x the F(4,3) matrix for R = 4 (the kernel applies B^T / 4); |U| <= 4 (2) max |w| -> S from that bound
+__device__ __forceinline__ void relayout_split_elem(const float* __restrict__ w, int Cin, int Cout, int flc, int MT, long long total,
                                                     unsigned short* __restrict__ wr, int dgrad, long long e0, int max_slot, int nslot) {
+  const int fl = flc & 15, R = flc >> 4;
   const int NP = npw_of(fl);
   float S = 1.0f;
   if (fl == 2) {
     unsigned mx = 0;
     for (int i = 0; i < nslot; ++i) mx = max(mx, reinterpret_cast<const unsigned*>(wr + total)[max_slot + i]);
-    S = f16_weight_scale(__builtin_bit_cast(float, mx));
+    S = f16_weight_scale(__builtin_bit_cast(float, mx) * (R == 4 ? 4.0f : R == 2 ? 2.0f : 1.0f));
     if (e0 == 0) reinterpret_cast<float*>(wr + total)[0] = 1.0f / S;
   }
   if (e0 >= total) return;
+  const int NT = R ? R + 2 : 3;
   const int e = (int)(e0 & 7), row = (int)((e0 >> 3) & 31), half = (int)((e0 >> 8) & 1);
   long long r = e0 >> 9;
   const int mt = (int)(r % MT); r /= MT;
   const int pl = (int)(r % NP); r /= NP;
   const int dx = (int)(r % 3); r /= 3;
-  const int dy = (int)(r % 3); r /= 3;
+  const int dy = (int)(r % NT); r /= NT;
   const int nch = Cin / KC;
   const int chunk = (int)(r % nch);
   const int cb = (int)(r / nch);
   const int co = (cb * MT + mt) * 32 + row, ci = chunk * KC + 8 * half + e;
   float v = 0.0f;
-  if (co < Cout) v = dgrad ? w[((size_t)ci * Cout + co) * 9 + (2 - dy) * 3 + (2 - dx)] : w[((size_t)co * Cin + ci) * 9 + dy * 3 + dx];
+  if (co < Cout) {
+    if (R) {
+      const float* g = w + ((size_t)co * Cin + ci) * 9 + dx;
+      const double g0 = g[0], g1 = g[3], g2 = g[6];
+      double u;
+      if (R == 4) {
+        switch (dy) {
+          case 0: u = g0; break;
+          case 1: u = -(g0 + g1 + g2) * (2.0 / 3.0); break;
+          case 2: u = -(g0 - g1 + g2) * (2.0 / 3.0); break;
+          case 3: u = g0 * (1.0 / 6.0) + g1 * (1.0 / 3.0) + g2 * (2.0 / 3.0); break;
+          case 4: u = g0 * (1.0 / 6.0) - g1 * (1.0 / 3.0) + g2 * (2.0 / 3.0); break;
+          default: u = 4.0 * g2; break;
+        }
+      } else {
+        switch (dy) {
+          case 0: u = g0; break;
+          case 1: u = 0.5 * (g0 + g1 + g2); break;
+          case 2: u = 0.5 * (g0 - g1 + g2); break;
+          default: u = g2; break;
+        }
+      }
+      v = (float)u;
+    } else {
+      v = dgrad ? w[((size_t)ci * Cout + co) * 9 + (2 - dy) * 3 + (2 - dx)] : w[((size_t)co * Cin + ci) * 9 + dy * 3 + dx];
+    }
+  }
   wr[e0] = fl == 2 ? f16_piece(v, pl, S) : bf16_piece(v, pl, fl == 1);
 }
 
@@ -207,7 +238,7 @@ __global__ void __launch_bounds__(256) weight_absmax_kernel(const float* __restr
 constexpr int ABSMAX_SPLIT = 8;
 __global__ void __launch_bounds__(256) weight_absmax_multi_kernel(const long long* __restrict__ jobs) {
   const long long* jb = jobs + (size_t)blockIdx.x * 8;
-  if ((int)(jb[4] & 0xff) != 2) return;
+  if ((int)(jb[4] & 0xf) != 2) return;
   const long long n = jb[2] * jb[3] * 9;
   const unsigned m = absmax_wave(reinterpret_cast<const float*>(jb[0]), n, (long long)blockIdx.y * 256 + threadIdx.x, (long long)ABSMAX_SPLIT * 256);
   __shared__ unsigned part[4];
@@ -971,22 +1002,26 @@ namespace c2m {
 namespace conv {
 
 // np = flavour: 3 bf16 x 3, 1 bf16, 2 f16 x 2 (image + 256-byte tail holding 1/S)
-static size_t split_image_bytes(int Cin, int Cout, int np) {
+// np = pieces code: 3 / 1 / 2, or 2 | R << 4 (R = 4, 2): the Winograd F(R,3)-along-y images (Cout % 64 == 0)
+static size_t split_image_bytes(int Cin, int Cout, int npc) {
+  const int np = npc & 15, R = npc >> 4;
   if (Cin <= 0 || Cout <= 0 || Cin % split::KC != 0 || (np != 1 && np != 2 && np != 3)) return 0;
+  if (R != 0 && (np != 2 || (R != 4 && R != 2) || Cout % 64 != 0)) return 0;
   const int MT = Cout <= 32 ? 1 : 2, ncb = (Cout + 32 * MT - 1) / (32 * MT);
-  return (size_t)ncb * (Cin / split::KC) * 9 * split::npw_of(np) * MT * 1024;
+  return (size_t)ncb * (Cin / split::KC) * (R ? R + 2 : 3) * 3 * split::npw_of(np) * MT * 1024;
 }
 
 size_t split_relayout_bytes(int Cin, int Cout, int np) {
   const size_t b = split_image_bytes(Cin, Cout, np);
-  return b == 0 ? 0 : b + (np == 2 ? 256 : 0);
+  return b == 0 ? 0 : b + ((np & 15) == 2 ? 256 : 0);
 }
 
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad) {
   const size_t bytes = split_image_bytes(Cin, Cout, np);
   if (bytes == 0) return C2M_ERR_UNSUPPORTED;
   const long long total = (long long)(bytes / 2);
-  if (np == 2) {   // per-tensor scale: max |w| -> tail of the image
+  if ((np >> 4) != 0 && dgrad) return C2M_ERR_UNSUPPORTED;
+  if ((np & 15) == 2) {   // per-tensor scale: max |w| -> tail of the image
     const long long n = (long long)Cin * Cout * 9;
     (void)hipMemsetAsync(reinterpret_cast<char*>(wr) + bytes, 0, 256, st);
     hipLaunchKernelGGL(split::weight_absmax_kernel, dim3((unsigned)std::min<long long>(64, (n + 4095) / 4096)), dim3(256), 0, st, weight, n,

@@ -16,22 +16,23 @@
 // (each transform-domain accumulator sums a third / a ninth of the products of a direct accumulator; measured in
 // tests/test_conv_gpu.py, predicted by scripts/sim_wino16_numerics.py before the kernel was written).
 //
-// Mapping: one workgroup = 4 waves, ONE per SIMD (the R + 2 transform-domain accumulators of a 64-cout tile are (R + 2) x 2 x 16
-// = 192 (128) registers: the unified 512-entry file at one wave per SIMD); tile = 30 x 4R output pixels x 64 couts:
-//   * wave w owns output rows [R w, R w + R) of the tile: accumulators acc[t][mt], t = 0 .. R+1, mt = 0, 1;
+// Mapping: one workgroup = 8 waves, two per SIMD, ONE workgroup per CU; tile = 30 x 4R output pixels x 64 couts:
+//   * wave w owns output rows [R g, R g + R) of the tile, g = w >> 1, and cout tile mt = w & 1: accumulators acc[t], t = 0 .. R+1
+//     (96 registers for R = 4; the whole wave stays below 256 registers, so that two waves share a SIMD and one's transform /
+//     split / epilogue instructions issue while the other's matrix instructions run);
 //   * the MFMA's 32 pixel columns are the 32 halo columns x0 - 1 .. x0 + 30 shifted by the tap: 30 valid output columns (the
-//     34-column halo of a 32-wide tile would leave 16 of 272 load slots to a second, almost empty round of R + 2 loads);
-//   * K in chunks of 16 input channels.  Lane (column c, channel quad q, half h) of the workgroup fetches the 2R + 2 halo rows
-//     of row groups 2h, 2h + 1 as fp32 (buffer_load_dwordx4, hardware zero fill) TWO chunks ahead into one of two register
-//     sets, transforms + splits them ONE chunk ahead (one (row group, t) item per tap of units 0 .. R, riding in the MFMA
-//     groups) into the other of two plane buffers [plane][k half][row group][t][32 columns][8 x f16];
+//     34-column halo of a 32-wide tile would leave 32 of 544 load slots to a third, almost empty round of R + 2 loads);
+//   * K in chunks of 16 input channels.  Lane (column c, channel quad q) of wave pair g fetches the R + 2 halo rows of row group
+//     g as fp32 (buffer_load_dwordx4, hardware zero fill) more than a chunk ahead, transforms + splits them ONE chunk ahead
+//     (item t in tap t of the chunk, riding in the MFMA groups; the registers re-load with the chunk after in taps T .. 2T-1)
+//     into the other of two plane buffers [plane][k half][row group][t][32 columns][8 x f16];
 //   * a unit = one transform position t with its three taps dx; its weight images U_t[dx] (split once per weight version by
 //     conv3x3_relayout_split_kernel, fl = 2 | R << 4) stream by LDS-DMA into a ring of FOUR slots three units ahead, landed
-//     TWO units ahead -- so the A operands of a unit's first tap are prefetched during the previous unit's last tap like
-//     every other operand (with one wave per SIMD nobody else covers an exposed LDS latency);
-//   * per tap: 4 A + 2 B ds_read_b128 (one tap ahead, two register sets) feed 6 MFMAs (3 products x 2 cout tiles);
+//     TWO units ahead -- the A operands of a unit's first tap are prefetched during the previous unit's last tap like every
+//     other operand (both waves of a SIMD run the same stream: nobody else covers an exposed LDS latency);
+//   * per tap and wave: 2 A + 2 B ds_read_b128 (one tap ahead, two register sets) feed 3 MFMAs (the three f16 x 2 products);
 //   * one barrier per unit; persistent tiles, XCD-aware order; epilogue: A^T, 1/S, bias, activation, residuals, 16-byte stores.
-// LDS (R = 4): planes 2 x 48.25 KiB + ring 4 x 12 KiB + bias = 144.75 KiB; R = 2: 2 x 32.25 + 48 = 112.75 KiB.
+// LDS (R = 4): planes 2 x 48.25 KiB + ring 4 x 12 KiB + dummy + bias = 145.75 KiB; R = 2: 2 x 32.25 + 48 + 1.25 = 113.75 KiB.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -56,9 +57,8 @@ constexpr float F16_LO_SCALE = 2048.0f;   // the low piece of an f16 x 2 operand
 
 template <int R>
 struct Geo {
-  static constexpr int T = R + 2;            // transform positions = units per chunk
+  static constexpr int T = R + 2;            // transform positions = units per chunk = halo rows of a row group
   static constexpr int TH = 4 * R;           // output rows of a tile
-  static constexpr int NROW = 2 * R + 2;     // halo rows a lane fetches (row groups 2h, 2h + 1)
   static constexpr int NSLAB = 4 * T;        // (row group, t) slabs of 32 columns x 16 B
   // one (plane, k half) array; + 64: (i) the two k halves of a ds_write_b64 group land on disjoint banks (== 64 mod 128),
   // (ii) the dx = 1, 2 shifted reads of the last slab stay inside the allocation (they feed output columns 30, 31: discarded)
@@ -66,13 +66,14 @@ struct Geo {
   static constexpr int PLB = 4 * KH;         // one plane buffer: [plane 2][k half 2]
   static constexpr float DOMAIN = R == 4 ? 26200.0f : 32760.0f;   // |V| <= 2.5 (2) max |d| must stay below 65520
 };
-constexpr int MT = 2, MW = 64;
+constexpr int MW = 64;                // couts per workgroup (two 32-row MFMA tiles, one per wave of a pair)
 constexpr int NRING = 4;
-constexpr int WTAP = 2 * MT * 1024;   // one tap's weight image [image 2][mt][k half][32 rows][16 B]
+constexpr int WTAP = 2 * 2 * 1024;    // one tap's weight image [image 2][mt 2][k half][32 rows][16 B]
 constexpr int WUNIT = 3 * WTAP;       // unit = one transform position, taps dx = 0, 1, 2
-constexpr int NW_W = WUNIT / 1024 / 4;   // LDS-DMA instructions per wave and unit (3)
+constexpr int NWI = WUNIT / 1024;     // LDS-DMA instructions per unit (12)
+constexpr int NW_W = 2;               // per wave: waves 0..5 move pieces 2w, 2w + 1; waves 6, 7 pad with dummies (uniform vmcnt counts)
 
-size_t lds_bytes(int R) { return (size_t)2 * (R == 4 ? Geo<4>::PLB : Geo<2>::PLB) + (size_t)NRING * WUNIT + 256; }
+size_t lds_bytes(int R) { return (size_t)2 * (R == 4 ? Geo<4>::PLB : Geo<2>::PLB) + (size_t)NRING * WUNIT + 1024 + 256; }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -89,6 +90,27 @@ template <int IMM>
 __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
   asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
 }
+// The halo rows are fetched by an OPAQUE instruction: the compiler's own vmcnt bookkeeping cannot count across the chunk loop's
+// back edge and put `s_waitcnt vmcnt(0)` in front of every transform item -- i.e. behind the weight DMAs just issued.  The
+// data is guaranteed by the unit-end waits instead (see there).  "+v": the destination is the register the previous chunk's
+// rows lived in -- the re-load happens in place, there is nothing for the register allocator to copy.
+// The descriptor travels as four words that are made scalar right at the instruction (v_readfirstlane: under SGPR pressure the
+// compiler otherwise keeps a loop-carried descriptor in vector registers and hands THOSE to the "s" operand).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct RsrcWords { int w0, w1, w2; };
+__device__ __forceinline__ RsrcWords rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  return RsrcWords{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes};
+}
+__device__ __forceinline__ void buf_load128f(f32x4& d, unsigned voff, const RsrcWords& rw, int soff) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane(rw.w0);
+  r[1] = __builtin_amdgcn_readfirstlane(rw.w1);
+  r[2] = __builtin_amdgcn_readfirstlane(rw.w2);
+  r[3] = 0x00020000;
+  const int so = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(d) : "v"(voff), "s"(r), "s"(so) : "memory");
+}
 __device__ __forceinline__ void split2_f16(const f32x4 v, u32x2& p0, u32x2& p1) {
   const f16x4 h0 = __builtin_convertvector(v, f16x4);
   const f32x4 r = (v - __builtin_convertvector(h0, f32x4)) * F16_LO_SCALE;
@@ -104,19 +126,18 @@ __device__ __forceinline__ f32x4 fma4(float a, const f32x4 x, const f32x4 y) {  
 }
 
 template <int R>
-__global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
+__global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
   using GE = Geo<R>;
-  constexpr int T = GE::T, TH = GE::TH, NROW = GE::NROW, KH = GE::KH, PLB = GE::PLB;
-  constexpr int NTAP = 3 * T;            // taps per chunk
-  constexpr int NITEM = 2 * T;           // (row group of this lane, t) transform + split items per chunk
-  static_assert(NITEM <= 3 * (T - 1) && NROW <= 3 * (T - 1), "items and raw loads fit the taps of units 0 .. T-2");
+  constexpr int T = GE::T, TH = GE::TH, KH = GE::KH, PLB = GE::PLB;
+  static_assert(2 * T <= 3 * (T - 1), "items (taps 0..T-1) and raw re-loads (taps T..2T-1) fit the taps of units 0 .. T-2");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned pl_base = lds0, w_base = lds0 + 2 * PLB, bias_lds = w_base + NRING * WUNIT;
+  const unsigned pl_base = lds0, w_base = lds0 + 2 * PLB, dummy = w_base + NRING * WUNIT, bias_lds = dummy + 1024;
 
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wv >> 1, lx = (wv & 1) * 16 + (l >> 2), q = l & 3;   // loading role: halo column lx, channel quad q, row-group pair
+  const int rg = wv >> 1, mtw = wv & 1;           // MFMA role: row group, cout tile
+  const int lx = mtw * 16 + (l >> 2), q = l & 3;  // loading role: halo column lx and channel quad q of row group rg
   const int ntile = p.tiles_x * p.tiles_y * p.B;
   const int tile_first = xcd_remap(blockIdx.x, gridDim.x) * p.tpw;
   const int ntl = min(p.tpw, ntile - tile_first);
@@ -125,20 +146,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
   const int G = ntl * p.nchunks;        // chunks of this workgroup
   const int NU = G * T;                 // units of this workgroup
 
-  // ---- weights: unit u of this cout block (WUNIT contiguous bytes) -> ring slot u & 3 by LDS-DMA, wave w moves pieces [3w, 3w + 3)
+  // ---- weights: unit u of this cout block (WUNIT contiguous bytes) -> ring slot u & 3 by LDS-DMA, wave w moves pieces 2w, 2w + 1
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
   const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
   int wsoff = 0;   // byte offset of the unit the NEXT issue fetches (wraps per tile)
   auto issue_w_piece = [&](unsigned slot_off, int i) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(w_base + slot_off + (unsigned)(wv * NW_W + i) * 1024u), 16,
-                                             wvoff, wsoff + i * 1024, 0, 0);
+    const int n = wv * NW_W + i;
+    const unsigned dst = n < NWI ? w_base + slot_off + (unsigned)n * 1024u : dummy;
+    // (beyond the image: reads the next unit / zeros past the end of the buffer, lands in the dummy page)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff + i * 1024, 0, 0);
   };
   auto issue_w_done = [&]() __attribute__((always_inline)) {
     wsoff += WUNIT;
     if (wsoff == UT * WUNIT) wsoff = 0;
   };
 
-  // ---- halo rows: lane (lx, q, half) fetches rows 2R*half .. 2R*half + 2R + 1 of the (4R + 2)-row halo, column x0 - 1 + lx
+  // ---- halo rows: lane (lx, q) of row group rg fetches rows R rg .. R rg + R + 1 of the (4R + 2)-row halo, column x0 - 1 + lx
   struct TileCoord { int b, ty, tx; };
   auto tc_init = [&](int tile) __attribute__((always_inline)) {
     TileCoord t;
@@ -155,60 +178,63 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
   };
   TileCoord dma_tc = tc_init(tile_first), epi_tc = dma_tc;
   int dma_c = 0;            // chunk (inside its tile) the next issue_in_begin() sets up
-  unsigned ivoff[NROW];
+  unsigned ivoff[T];
   int iy0 = 0, ix0 = 0, in_soff = 0;
   bool in_first = true;
-  __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.src[0].ptr, 0u), rs1 = rs0;
+  RsrcWords rs = rsrc_words(p.src[0].ptr, 0u);   // the source the current chunk's rows come from
+  int dma_b = 0;
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
     const int ix = ix0 - 1 + lx;
 #pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-      const int iy = iy0 - 1 + 2 * R * half + i;
+    for (int i = 0; i < T; ++i) {
+      const int iy = iy0 - 1 + R * rg + i;
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       ivoff[i] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * q) * 4u : kOOB;
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
     const unsigned bytes = (unsigned)((p.H - 1) * S.row_pitch + (p.W - 1) * S.pix_pitch + S.C) * 4u;
-    return make_rsrc(S.ptr + (long long)b * S.img_pitch, bytes);
+    return rsrc_words(S.ptr + (long long)b * S.img_pitch, bytes);
   };
   auto issue_in_begin = [&]() __attribute__((always_inline)) {   // the next chunk of the workgroup's stream
     const int c0 = dma_c * KC;
     in_first = c0 < p.src[0].C;
     if (++dma_c == p.nchunks) dma_c = 0;
     if (c0 == 0) {
-      iy0 = dma_tc.ty * TH; ix0 = dma_tc.tx * TWO;
-      rs0 = src_rsrc(p.src[0], dma_tc.b);
-      rs1 = src_rsrc(p.src[1], dma_tc.b);
+      iy0 = dma_tc.ty * TH; ix0 = dma_tc.tx * TWO; dma_b = dma_tc.b;
+      rs = src_rsrc(p.src[0], dma_b);
       tc_next(dma_tc);
       set_source(p.src[0]);
     } else if (c0 == p.src[0].C) {
+      rs = src_rsrc(p.src[1], dma_b);
       set_source(p.src[1]);
     }
     in_soff = (in_first ? c0 : c0 - p.src[0].C) * 4;
   };
-  f32x4 raw[2][NROW];   // two register sets: chunk c lives in set c & 1 from chunk c-2 (fetch) to chunk c-1 (transform)
+  f32x4 raw[T] = {};   // the lane's halo rows of ONE chunk: fetched in taps T..2T-1 of chunk c-2, transformed in taps 0..T-1 of chunk c-1
   float amax = 0.0f;
-  auto load_row = [&](auto setc, auto ic) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value, I = decltype(ic)::value;
-    raw[SET][I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_first ? rs0 : rs1, (int)ivoff[I], in_soff, 0));
+  auto load_row = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    buf_load128f(raw[I], ivoff[I], rs, in_soff);
   };
 
-  // ---- transform + split item K = a*T + t of the lane's row group a (of its pair) from register set SET -> plane buffer at
-  // byte offset pb: V_t = sum_i BT[t][i] * raw[R a + i], two f16 pieces, 8 bytes each at [plane][q >> 1][slab][lx][q & 1]
-  const unsigned cwr = pl_base + (q >> 1) * KH + (2 * half * T) * 512 + lx * 16 + (q & 1) * 8;
+  // ---- transform + split item t of the lane's row group -> plane buffer at byte offset pb: V_t = sum_i BT[t][i] * raw[i],
+  // two f16 pieces, 8 bytes each at [plane][q >> 1][slab rg*T + t][lx][q & 1]
+  const unsigned cwr = pl_base + (q >> 1) * KH + (rg * T) * 512 + lx * 16 + (q & 1) * 8;
   f32x4 hold = {0.0f, 0.0f, 0.0f, 0.0f};   // V_2 / V_4, computed with V_1 / V_3 (shared sub-expressions)
-  auto item = [&](auto setc, auto kc, unsigned pb) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value, K = decltype(kc)::value, A = K / T, t = K % T;
-    const f32x4* d = &raw[SET][R * A];
+  auto item = [&](auto tc, unsigned pb) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    const f32x4* d = raw;
     f32x4 v;
+    if constexpr (t == 0) {   // (range check: every row, once per chunk)
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, __builtin_fabsf(d[i][e]));
+    }
     if constexpr (R == 4) {
       if constexpr (t == 0) {
         v = fma4(0.25f, d[4], fma4(-1.25f, d[2], d[0]));
-#pragma unroll
-        for (int i = 0; i < T; ++i)   // (range check: every row of this row group, once)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) amax = fmaxf(amax, __builtin_fabsf(d[i][e]));
       } else if constexpr (t == 1) {
         const f32x4 P = fma4(0.25f, d[4], -d[2]), Q = fma4(0.25f, d[3], -d[1]);
         v = P + Q;
@@ -223,56 +249,45 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
         v = hold;
       }
     } else {
-      if constexpr (t == 0) {
-        v = d[0] - d[2];
-#pragma unroll
-        for (int i = 0; i < T; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) amax = fmaxf(amax, __builtin_fabsf(d[i][e]));
-      } else if constexpr (t == 1) {
-        v = d[1] + d[2];
-      } else if constexpr (t == 2) {
-        v = d[2] - d[1];
-      } else {
-        v = d[1] - d[3];
-      }
+      if constexpr (t == 0) v = d[0] - d[2];
+      else if constexpr (t == 1) v = d[1] + d[2];
+      else if constexpr (t == 2) v = d[2] - d[1];
+      else v = d[1] - d[3];
     }
     u32x2 p0, p1;
     split2_f16(v, p0, p1);
-    lds_write64<K * 512>(cwr + pb, p0);
-    lds_write64<K * 512 + 2 * KH>(cwr + pb, p1);
+    lds_write64<t * 512>(cwr + pb, p0);
+    lds_write64<t * 512 + 2 * KH>(cwr + pb, p1);
   };
 
-  // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, image pl, cout tile mt;
-  //                B = column j + dx of slab (row group wv, t), k half hi, plane pl
-  const unsigned abase = w_base + hi * 512 + j * 16;
-  const unsigned bbase = pl_base + hi * KH + (wv * T) * 512 + j * 16;
-  f16x8 A[2][2][MT], Bq[2][2];   // two operand sets: tap n = 3t + dx multiplies set n & 1
-  f16x8 Ad[MT];                  // 2^-11 wA of the current tap
-  auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
-    lds_read128<DX * WTAP + K * 1024>(A[SET][K / MT][K % MT], aslot);
+  // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, image pl, this wave's cout tile;
+  //                B = column j + dx of slab (row group rg, t), k half hi, plane pl
+  const unsigned abase = w_base + mtw * 1024 + hi * 512 + j * 16;
+  const unsigned bbase = pl_base + hi * KH + (rg * T) * 512 + j * 16;
+  f16x8 A[2][2], Bq[2][2];   // [set][image / plane]: tap n = 3t + dx multiplies set n & 1
+  f16x8 Ad;                  // 2^-11 wA of the current tap
+  auto load_a = [&](auto setc, auto dxc, auto plc, unsigned aslot) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, PL = decltype(plc)::value;
+    lds_read128<DX * WTAP + PL * 2048>(A[SET][PL], aslot);
   };
   auto load_b = [&](auto setc, auto tc, auto dxc, auto plc, unsigned bcur) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value, TT = decltype(tc)::value, DX = decltype(dxc)::value, PL = decltype(plc)::value;
     lds_read128<PL * 2 * KH + TT * 512 + DX * 16>(Bq[SET][PL], bcur);
   };
 
-  float w_sinv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wr) + (size_t)gridDim.y * UT * WUNIT);   // 1/S behind the images
+  const float w_sinv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wr) + (size_t)gridDim.y * UT * WUNIT);   // 1/S behind the images
   if (tid < MW) {
     const int co = cb * MW + tid;
     *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
   }
-  f32x16 acc[T][MT];
+  f32x16 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   // ------------------------------------------------------------------------------------------------------------------
-  // prologue: weights of units 0, 1, 2; chunk 0 fetched into set 0, transformed into plane buffer 0; chunk 1 fetched into set 1
+  // prologue: weights of units 0, 1, 2; chunk 0 fetched, transformed into plane buffer 0; chunk 1 fetched
   // ------------------------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < NRING - 1; ++u)
@@ -282,108 +297,97 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
       issue_w_done();
     }
   issue_in_begin();
-  static_for<0, NROW>([&](auto ic) __attribute__((always_inline)) { load_row(std::integral_constant<int, 0>(), ic); });
+  static_for<0, T>([&](auto ic) __attribute__((always_inline)) { load_row(ic); });
+  wait_vmcnt<0>();
+  static_for<0, T>([&](auto tc) __attribute__((always_inline)) { item(tc, 0u); });
   if (G > 1) {
     issue_in_begin();
-    static_for<0, NROW>([&](auto ic) __attribute__((always_inline)) { load_row(std::integral_constant<int, 1>(), ic); });
+    static_for<0, T>([&](auto ic) __attribute__((always_inline)) { load_row(ic); });
   }
-  static_for<0, NITEM>([&](auto kc) __attribute__((always_inline)) { item(std::integral_constant<int, 0>(), kc, 0u); });
   // first operands: A of (unit 0, dx 0), B of (t 0, dx 0) -- after everything above has landed and been published
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  static_for<0, 2 * MT>([&](auto kc) __attribute__((always_inline)) {
-    load_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, abase);
-  });
   static_for<0, 2>([&](auto plc) __attribute__((always_inline)) {
+    load_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), plc, abase);
     load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), plc, bbase);
   });
 
   // ------------------------------------------------------------------------------------------------------------------
-  // one chunk = T units of three taps.  PAR = chunk parity: plane buffer PAR is multiplied, items transform register set
-  // 1 - PAR (chunk gc + 1) into plane buffer 1 - PAR, raw loads of chunk gc + 2 refill set PAR.
+  // one chunk = T units of three taps: plane buffer gc & 1 is multiplied; items (taps 0..T-1) transform the registers (chunk
+  // gc + 1) into the other plane buffer; the registers re-load with chunk gc + 2 in taps T..2T-1.
   // ------------------------------------------------------------------------------------------------------------------
-  auto chunk = [&](auto parc, int gc) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(parc)::value;
-    const bool has_next = gc + 1 < G, more_in = gc + 2 < G;
-    const unsigned bcur = bbase + PAR * PLB, bnext = bbase + (1 - PAR) * PLB;
-    if (more_in) issue_in_begin();
-    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      const int u = gc * T + t;
-      constexpr int slot = (PAR * T + t) & 3;                       // (gc*T + t) & 3: T even
-      constexpr unsigned slot_cur = slot * WUNIT, slot_n1 = ((slot + 1) & 3) * WUNIT, slot_n3 = ((slot + 3) & 3) * WUNIT;
-      const unsigned aslot = abase + slot_cur;
-      const bool do_w = u + NRING - 1 < NU;
-      static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
-        constexpr int dx = decltype(dxc)::value, n = 3 * t + dx;
-        constexpr int set = n & 1, nset = set ^ 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 3>([&](auto gcnt) __attribute__((always_inline)) {
-          constexpr int g = decltype(gcnt)::value;
-          // ---- next tap's operands, three reads per group in groups 0 and 1
-          if constexpr (g < 2) {
-            static_for<3 * g, 3 * g + 3>([&](auto kc) __attribute__((always_inline)) {
-              constexpr int K = decltype(kc)::value;   // 0..3: A images, 4..5: B planes
-              if constexpr (dx < 2) {
-                if constexpr (K < 4) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), kc, aslot);
-                else load_b(std::integral_constant<int, nset>(), tc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - 4>(), bcur);
-              } else {
-                // first tap of the next unit: its weights landed two units ago; at the chunk's end the B operand comes from the
-                // other plane buffer, complete since the barrier of unit T-2
-                if constexpr (K < 4) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, 0>(), kc, abase + slot_n1);
-                else if constexpr (t < T - 1) load_b(std::integral_constant<int, nset>(), std::integral_constant<int, t + 1>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - 4>(), bcur);
-                else load_b(std::integral_constant<int, nset>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - 4>(), bnext);
-              }
-            });
-          }
-          if constexpr (dx == 0) {
-            if (do_w) issue_w_piece(slot_n3, g);
-          }
-          if constexpr (g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
-            const f16x8 sc = {(_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE),
-                              (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE)};
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) Ad[mt] = A[set][0][mt] * sc;
-          }
-          if constexpr (g == 1) {
-            if constexpr (n < NITEM) {
-              if (has_next) item(std::integral_constant<int, 1 - PAR>(), std::integral_constant<int, n>(), (unsigned)((1 - PAR) * PLB));
-            }
-            if constexpr (n < NROW) {
-              if (more_in) load_row(std::integral_constant<int, PAR>(), std::integral_constant<int, n>());
-            }
-          }
-          // products: g = 0: w1 . x0, g = 1: (2^-11 wA) . x1', g = 2: wA . x0 (smallest terms first)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f16x8 av = g == 0 ? A[set][1][mt] : (g == 1 ? Ad[mt] : A[set][0][mt]);
-            acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, Bq[set][g == 1 ? 1 : 0], acc[t][mt], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (dx == 0) {
-          if (do_w) issue_w_done();
-        }
-      });
-      // ---- unit end: own LDS writes done; everything issued BEFORE this unit has landed (the weights of unit u + 2 among
-      // it); still in flight may be what this unit issued: W(u+3) x 3 and its raw loads.  Barrier: publishes W(u+2) and
-      // (unit T-2) the other plane buffer, frees ring slot u & 3.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      constexpr int nraw = NROW - 3 * t >= 3 ? 3 : (NROW - 3 * t > 0 ? NROW - 3 * t : 0);
-      if (do_w && more_in) wait_vmcnt<NW_W + nraw>();
-      else if (do_w) wait_vmcnt<NW_W>();
-      else if (more_in) wait_vmcnt<nraw>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-    });
-  };
-
+  unsigned slot = 0;   // ring slot (index) of the current unit
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      if (gc & 1) chunk(std::integral_constant<int, 1>(), gc);
-      else chunk(std::integral_constant<int, 0>(), gc);
+      const bool has_next = gc + 1 < G, more_in = gc + 2 < G;
+      const unsigned pcur = (unsigned)(gc & 1) * PLB, pnext = PLB - pcur;
+      const unsigned bcur = bbase + pcur, bnext = bbase + pnext;
+      static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const int u = gc * T + t;
+        const unsigned aslot = abase + slot * WUNIT, aslot_n1 = abase + ((slot + 1) & 3) * WUNIT, wslot_n3 = ((slot + 3) & 3) * WUNIT;
+        const bool do_w = u + NRING - 1 < NU;
+        static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
+          constexpr int dx = decltype(dxc)::value, n = 3 * t + dx;
+          constexpr int set = n & 1, nset = set ^ 1;
+          if constexpr (n == T) {
+            if (more_in) issue_in_begin();   // (the chunk the re-loads of taps T..2T-1 fetch)
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, 3>([&](auto gcnt) __attribute__((always_inline)) {
+            constexpr int g = decltype(gcnt)::value;
+            // ---- next tap's operands: group 0 reads its A images, group 1 its B planes
+            if constexpr (g == 0) {
+              static_for<0, 2>([&](auto plc) __attribute__((always_inline)) {
+                if constexpr (dx < 2) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), plc, aslot);
+                else load_a(std::integral_constant<int, nset>(), std::integral_constant<int, 0>(), plc, aslot_n1);   // next unit: its weights landed two units ago
+              });
+            } else if constexpr (g == 1) {
+              static_for<0, 2>([&](auto plc) __attribute__((always_inline)) {
+                if constexpr (dx < 2) load_b(std::integral_constant<int, nset>(), tc, std::integral_constant<int, dx + 1>(), plc, bcur);
+                else if constexpr (t < T - 1) load_b(std::integral_constant<int, nset>(), std::integral_constant<int, t + 1>(), std::integral_constant<int, 0>(), plc, bcur);
+                else load_b(std::integral_constant<int, nset>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), plc, bnext);   // next chunk: that buffer is complete since the barrier of unit T-2
+              });
+            }
+            if constexpr (dx == 0 && g < NW_W) {
+              if (do_w) issue_w_piece(wslot_n3, g);
+            }
+            if constexpr (g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
+              const f16x8 sc = {(_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE),
+                                (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE), (_Float16)(1.0f / F16_LO_SCALE)};
+              Ad = A[set][0] * sc;
+            }
+            if constexpr (g == 1) {
+              if constexpr (n < T) {
+                if (has_next) item(std::integral_constant<int, n>(), pnext);
+              } else if constexpr (n < 2 * T) {
+                if (more_in) load_row(std::integral_constant<int, n - T>());
+              }
+            }
+            // products: g = 0: w1 . x0, g = 1: (2^-11 wA) . x1', g = 2: wA . x0 (smallest terms first)
+            const f16x8 av = g == 0 ? A[set][1] : (g == 1 ? Ad : A[set][0]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, Bq[set][g == 1 ? 1 : 0], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          if constexpr (dx == 0) {
+            if (do_w) issue_w_done();
+          }
+        });
+        // ---- unit end: own LDS writes done; everything issued BEFORE this unit has landed (the weights of unit u + 2 among
+        // it); still in flight may be what this unit issued: W(u+3) x NW_W and its raw re-loads.  Barrier: publishes W(u+2) and
+        // (units <= T-2) the other plane buffer's slabs, frees ring slot u & 3.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int lo = 3 * t > T ? 3 * t : T, hi_ = 3 * t + 3 < 2 * T ? 3 * t + 3 : 2 * T;
+        constexpr int nraw = hi_ > lo ? hi_ - lo : 0;   // re-loads issued in this unit's taps
+        if (do_w && more_in) wait_vmcnt<NW_W + nraw>();
+        else if (do_w) wait_vmcnt<NW_W>();
+        else if (more_in) wait_vmcnt<nraw>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1) & 3;
+      });
     }
     // ----------------------------------------------------------------------------------------------------------------
     // epilogue of the tile: y = A^T m per (cout, column), then 1/S, bias, activation, residuals, 16-byte stores
@@ -392,54 +396,67 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(Params p) {
     tc_next(epi_tc);
     const int x = x0 + j;
     const bool xok = j < TWO && x < p.W;
+    f32x4 o[R][4];   // [output row][cout quad pair qd]: couts 8 qd + 4 hi .. + 3 of this wave's cout tile
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (mtw * 32 + 8 * qd + 4 * hi) * 4);
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (mt * 32 + 8 * qd + 4 * hi) * 4);
-        f32x4 o[R];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * qd + e;
-          if constexpr (R == 4) {
-            const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r], m4 = acc[4][mt][r], m5 = acc[5][mt][r];
-            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-            o[0][e] = (m0 + s1) + s2;
-            o[1][e] = __builtin_fmaf(2.0f, d2, d1);
-            o[2][e] = __builtin_fmaf(4.0f, s2, s1);
-            o[3][e] = __builtin_fmaf(8.0f, d2, d1) + m5;
-          } else {
-            const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r];
-            o[0][e] = (m0 + m1) + m2;
-            o[1][e] = (m1 - m2) - m3;
-          }
-        }
-        const int co = cb * MW + mt * 32 + 8 * qd + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          f32x4 v = o[r] * w_sinv + bv;   // (power of two: exact)
-          if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-          } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.slope);
-          }
-          const int y = y0 + R * wv + r;
-          if (xok && y < p.H && co + 3 < p.Cout) {
-            const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co;
-            if (p.res1) v += *reinterpret_cast<const f32x4*>(p.res1 + opix);
-            if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + opix);
-            *reinterpret_cast<f32x4*>(p.out + opix) = v;
-          }
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * qd + e;
+        if constexpr (R == 4) {
+          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+          const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+          o[0][qd][e] = (m0 + s1) + s2;
+          o[1][qd][e] = __builtin_fmaf(2.0f, d2, d1);
+          o[2][qd][e] = __builtin_fmaf(4.0f, s2, s1);
+          o[3][qd][e] = __builtin_fmaf(8.0f, d2, d1) + m5;
+        } else {
+          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+          o[0][qd][e] = (m0 + m1) + m2;
+          o[1][qd][e] = (m1 - m2) - m3;
         }
       }
 #pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x4 v = o[r][qd] * w_sinv + bv;   // (power of two: exact)
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * p.slope);
+        }
+        o[r][qd] = v;
+      }
+    }
+    // one output row at a time: its residual pieces are fetched together (both waves of a SIMD are in their epilogues at the
+    // same time -- nothing else covers a load's latency), then added and stored
+    const int co_w = cb * MW + mtw * 32 + 4 * hi;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int y = y0 + R * rg + r;
+      const bool rok = xok && y < p.H;
+      const size_t opix = (size_t)b * p.out_img_pitch + (size_t)(rok ? y : 0) * p.out_row_pitch + (size_t)(rok ? x : 0) * p.out_pix_pitch + co_w;
+      f32x4 r1[4], r2[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const bool ok = rok && co_w + 8 * qd + 3 < p.Cout;
+        r1[qd] = (p.res1 && ok) ? *reinterpret_cast<const f32x4*>(p.res1 + opix + 8 * qd) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        r2[qd] = (p.res2 && ok) ? *reinterpret_cast<const f32x4*>(p.res2 + opix + 8 * qd) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        // (the reference adds the residuals one after the other: (conv + res1) + res2)
+        f32x4 v = o[r][qd];
+        if (p.res1) v += r1[qd];
+        if (p.res2) v += r2[qd];
+        if (rok && co_w + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(p.out + opix + 8 * qd) = v;
+      }
+    }
+#pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   }
   if (p.range_flag != nullptr && !(amax < GE::DOMAIN)) *p.range_flag = 1;   // (rare, idempotent store; inf / NaN count)
 }
@@ -455,7 +472,7 @@ int launch_wino16(hipStream_t st, Params p, int R) {
   const long long ntile = (long long)p.tiles_x * p.tiles_y * p.B;
   if (ntile > 0x7fffffffLL || (R != 4 && R != 2)) return C2M_ERR_INVALID_ARG;
   static const int env_tpw = [] { const char* e = getenv("C2M_CONV_TPW"); return e ? atoi(e) : 0; }();
-  const long long resident = 256;   // one workgroup per CU
+  const long long resident = 256;   // one workgroup (8 waves) per CU
   long long tpw = 1, best = -1;
   for (long long t = 1; t <= 16; ++t) {
     const long long wgs = ((ntile + t - 1) / t) * ncb;
@@ -470,10 +487,10 @@ int launch_wino16(hipStream_t st, Params p, int R) {
   int rc;
   if (R == 4) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino16::conv3x3_wino16_kernel<4>), ldsb, done4)) != C2M_OK) return rc;
-    hipLaunchKernelGGL(wino16::conv3x3_wino16_kernel<4>, grid, dim3(256), ldsb, st, p);
+    hipLaunchKernelGGL(wino16::conv3x3_wino16_kernel<4>, grid, dim3(512), ldsb, st, p);
   } else {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&wino16::conv3x3_wino16_kernel<2>), ldsb, done2)) != C2M_OK) return rc;
-    hipLaunchKernelGGL(wino16::conv3x3_wino16_kernel<2>, grid, dim3(256), ldsb, st, p);
+    hipLaunchKernelGGL(wino16::conv3x3_wino16_kernel<2>, grid, dim3(512), ldsb, st, p);
   }
   return check_launch();
 }

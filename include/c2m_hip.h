@@ -247,7 +247,7 @@ typedef struct c2m_conv_src {
 } c2m_conv_src;
 
 enum { C2M_CONV_DIRECT = 0, C2M_CONV_WINOGRAD_F23X = 1, C2M_CONV_WINOGRAD_F43X = 2, C2M_CONV_SPLIT_BF16X3 = 3, C2M_CONV_BF16 = 4,
-       C2M_CONV_SPLIT_F16X2 = 5 };
+       C2M_CONV_SPLIT_F16X2 = 5, C2M_CONV_WINO_F16X2_F43Y = 6, C2M_CONV_WINO_F16X2_F23Y = 7 };
 enum { C2M_OUT_NHWC = 0, C2M_OUT_NHWC_PIXEL_SHUFFLE2 = 1, C2M_OUT_NCHW = 2, C2M_OUT_DCN_HEAD = 3, C2M_OUT_NHWC_MAXPOOL2 = 4 };
 
 typedef struct c2m_conv3x3_desc {
@@ -293,7 +293,14 @@ typedef struct c2m_conv3x3_desc {
                               epilogue.  Error of the same class as the fp32 accumulation chain itself (tests/test_conv_gpu.py
                               holds it to the tolerance of the other fp32 kernels).  Domain: |x| < 65520 -- larger inputs give NaN
                               (never a silently wrong number); for such data use C2M_CONV_SPLIT_BF16X3 (full fp32 range).
-                              pieces = 2 (the image carries 1/S behind it) */
+                              pieces = 2 (the image carries 1/S behind it).
+                              C2M_CONV_WINO_F16X2_F43Y (6) / _F23Y (7): the same f16 x 2 arithmetic behind a Winograd F(4,3) / F(2,3)
+                              transform ALONG Y (csrc/conv3x3_wino16.hip): 1/2 (2/3) of the matrix instructions of (5).  C2M_OUT_NHWC
+                              only, Cout % 64 == 0, channels % 16 == 0, any H, W; `wr` from c2m_conv3x3_relayout_split_f32 with
+                              pieces = 2 | R << 4 (0x42 / 0x22).  The input transform runs in fp32 before the split, the weight
+                              transform in float64 before theirs, the output transform in fp32: error against float64 below (5)'s
+                              for F(2,3) and at the exact-fp32-MFMA kernel's level for F(4,3) (tests/test_conv_gpu.py holds both to
+                              (5)'s tolerances).  Domain |x| < 26200 (F43) / 32760 (F23), reported through range_flag as for (5) */
   int cout_offset;         /* DCN_HEAD: this call computes head channels [cout_offset, cout_offset + Cout) of cout_total */
   int cout_total;          /* (weights / bias passed are those rows only); 0 = the whole head in one call.  Lets a 216-channel
                               head run as 192 channels on 64-wide tiles + 24 on a 32-wide tile instead of 256 padded ones */
@@ -329,7 +336,8 @@ size_t c2m_conv3x3_relayout_wino_bytes(int Cin, int Cout);   /* 0 if unsupported
 int c2m_conv3x3_relayout_wino_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
 size_t c2m_conv3x3_relayout_wino4_bytes(int Cin, int Cout);  /* 0 if unsupported (Cin % 16, Cout % 64) */
 int c2m_conv3x3_relayout_wino4_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, float* wr);
-size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3, 1 or 2 (f16 x 2); 0 if unsupported (Cin % 16) */
+size_t c2m_conv3x3_relayout_split_bytes(int Cin, int Cout, int pieces);   /* pieces 3, 1 or 2 (f16 x 2), or 2 | R << 4 (0x42, 0x22: images
+                                                                             of C2M_CONV_WINO_F16X2_F43Y / _F23Y, Cout % 64 == 0); 0 if unsupported (Cin % 16) */
 int c2m_conv3x3_relayout_split_f32(c2m_stream_t stream, const float* weight, int Cin, int Cout, int pieces, void* wr);
 /* Many images per call (the per-forward refresh of a module's cached weight images from the parameters' current contents:
  * ~160 tensors of a RestorationNet in two launches instead of three per tensor).  `jobs` = DEVICE array [njobs][8] of int64:

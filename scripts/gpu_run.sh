@@ -11,6 +11,9 @@ mkdir -p $O
 for stage in "$@"; do
   case $stage in
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ;;
+    diag_w16)   (timeout 300 python scripts/diag_wino16.py; timeout 300 python scripts/diag_wino16.py f23) > $O/diag_wino16.log 2>&1 ;;
+    test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
+    bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
     test_conv)  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_conv.log ;;
     test_dcn)   timeout 900 python -m pytest tests/test_dcn_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_dcn.log ;;

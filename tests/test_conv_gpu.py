@@ -387,6 +387,119 @@ def test_conv3x3_split16_domain(ops, dev):
     assert e16 < 1e-5 * float(want.abs().max()) and e16 <= 1.5 * ed + 1e-7 * float(want.abs().max()), (e16, ed)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Winograd F(4,3) / F(2,3) ALONG Y on the f16 x 2 pieces (csrc/conv3x3_wino16.hip): "wino16" / "wino16_f23".  Channels-last
+# output, Cout % 64 == 0, any map size.  Held to the split kernel's own tolerances: 1e-5 * scale against float64 and <= 1.5 x the
+# exact-fp32-MFMA ("direct") kernel's distance from float64.
+# ---------------------------------------------------------------------------------------------------------------------
+WINO16_ALGOS = ("wino16", "wino16_f23")
+WINO16_CASES = [c for c in CASES + WINO_CASES if c[2] % 64 == 0] + [
+    (1, [16], 64, 8, 32, 0, 0),          # one chunk per tile: prologue / first-operand paths only
+    (1, [32], 64, 3, 5, 1, 0),           # map smaller than a tile in both directions
+    (2, [48, 16], 128, 17, 33, 2, 1),    # 16-channel source boundary inside the stream, two cout blocks, ragged tiles
+    (1, [64], 64, 64, 96, 1, 1),         # several tiles per workgroup
+    (1, [32], 64, 390, 392, 1, 0),       # > 256 workgroup slots: persistent workgroups, odd chunk count per stream position
+    (1, [16], 64, 384, 400, 2, 1),       # one-chunk tiles in a long stream (the plane-buffer / ring parities walk through every phase)
+    (1, [48], 64, 50, 61, 0, 2),         # three chunks per tile: odd number of units per tile (ring slot / plane buffer parity per tile)
+]
+
+
+@pytest.mark.parametrize("algo", WINO16_ALGOS)
+@pytest.mark.parametrize("case", WINO16_CASES)
+def test_conv3x3_wino16_matches_fp64_conv2d(ops, dev, case, algo):
+    B, cins, Cout, H, W, act, nres = case
+    xs = [_cl(_rand((B, c, H, W), dev, 410 + k)) for k, c in enumerate(cins)]
+    w = _rand((Cout, sum(cins), 3, 3), dev, 420, 1.0 / np.sqrt(9 * sum(cins)))
+    b = _rand((Cout,), dev, 421)
+    res = [_cl(_rand((B, Cout, H, W), dev, 430 + k)) for k in range(nres)]
+    kw = dict(act=act, slope=0.1, res1=res[0] if nres > 0 else None, res2=res[1] if nres > 1 else None)
+    got = ops.conv3x3(xs, w, b, algo=algo, **kw)
+    want = _ref(xs, w, b, act, 0.1, res)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got.double() - want).abs().max())
+    assert err < 1e-5 * scale, err
+    if algo == {7: "wino16", 8: "wino16_f23"}.get(ops._WINO16) and ops._SPLIT16:   # the automatic choice under a guard / explicit flavour
+        with ops.conv_flavour("f16x2"):
+            auto = ops.conv3x3(xs, w, b, fast=True, **kw)
+        assert torch.equal(auto, got)
+
+
+def test_conv3x3_wino16_is_as_accurate_as_the_fp32_mfma_kernel(ops, dev):
+    """Same criterion as the direct f16 x 2 kernel's: distance from float64 <= 1.5 x the exact-fp32-MFMA kernel's, in the
+    maximum and in the root-mean-square sense, on K = 9 * 256 products per output (N(0,1) inputs) and on non-negative
+    (post-ReLU-like) inputs, where a Winograd transform's intermediate magnitudes are least favourable."""
+    for kind in ("normal", "relu"):
+        x = _rand((1, 256, 32, 60), dev, 440)
+        if kind == "relu":
+            x = x.clamp_min(0)
+        x = _cl(x)
+        w, b = _rand((256, 256, 3, 3), dev, 441, 1.0 / 48.0), _rand((256,), dev, 442)
+        want = _ref([x], w, b, 0, 0.0, [])
+        outs = {a: ops.conv3x3(x, w, b, algo=a).double() for a in ("direct", "split16") + WINO16_ALGOS}
+        errs = {a: float((o - want).abs().max()) for a, o in outs.items()}
+        rms = {a: float((o - want).pow(2).mean().sqrt()) for a, o in outs.items()}
+        for a in WINO16_ALGOS:
+            assert errs[a] <= 1.5 * errs["direct"] + 1e-7, (kind, errs)
+            assert rms[a] <= 1.5 * rms["direct"], (kind, rms)
+        assert errs["wino16_f23"] <= 1.25 * errs["split16"] + 1e-7 and rms["wino16_f23"] <= 1.1 * rms["split16"], (kind, errs, rms)
+
+
+@pytest.mark.parametrize("algo", WINO16_ALGOS)
+@pytest.mark.parametrize("xs_,ws_", [(1e-3, 1.0), (1e3, 1.0), (1.0, 1e-6), (1.0, 1e5), (3e-3, 2e-4), (250.0, 37.0)])
+def test_conv3x3_wino16_scales(ops, dev, algo, xs_, ws_):
+    """Away from unit scale (activations 1e-3 ... 1e3, weights of any magnitude) the RELATIVE accuracy of the unit-scale case holds."""
+    x = _cl(_rand((1, 64, 16, 40), dev, 450)) * xs_
+    w, b = _rand((64, 64, 3, 3), dev, 451, 1.0 / 24.0) * ws_, _rand((64,), dev, 452) * (xs_ * ws_)
+    want = _ref([x], w, b, 0, 0.0, [])
+    scale = float(want.abs().max())
+    e16 = float((ops.conv3x3(x, w, b, algo=algo).double() - want).abs().max())
+    ed = float((ops.conv3x3(x, w, b, algo="direct").double() - want).abs().max())
+    assert e16 < 1e-5 * scale and e16 <= 1.5 * ed + 1e-7 * scale, (e16, ed, scale)
+
+
+@pytest.mark.parametrize("algo", WINO16_ALGOS)
+def test_conv3x3_wino16_domain_and_range_flag(ops, dev, algo):
+    """Domain |x| < 26200 (F(4,3)) / 32760 (F(2,3)): beyond it the kernel raises the range flag (the guarded module forwards then
+    recompute on bf16 x 3) -- below it, mixed magnitudes 1e-6 ... 3e3 keep the tolerance; zero weights give exactly the bias."""
+    x = _cl(_rand((1, 32, 8, 32), dev, 460))
+    w, b = _rand((64, 32, 3, 3), dev, 461, 0.06), _rand((64,), dev, 462)
+    assert not ops.range_flag_set(dev)
+    ops.conv3x3(x, w, b, algo=algo)
+    assert not ops.range_flag_set(dev)
+    xb = x.clone()
+    xb[0, 5, 4, 7] = 4.0e4
+    ops.conv3x3(_cl(xb), w, b, algo=algo)
+    assert ops.range_flag_set(dev) and not ops.range_flag_set(dev)     # reported, then cleared
+    z = ops.conv3x3(x, torch.zeros_like(w), b, algo=algo)
+    assert torch.equal(z, b.view(1, -1, 1, 1).expand_as(z))
+    mag = 10.0 ** (_rand((1, 32, 8, 32), dev, 463) * 2.5 - 1.0).clamp(-6.0, 3.5)
+    xm = _cl(x * mag)
+    want = _ref([xm], w, b, 0, 0.0, [])
+    e16 = float((ops.conv3x3(xm, w, b, algo=algo).double() - want).abs().max())
+    ed = float((ops.conv3x3(xm, w, b, algo="direct").double() - want).abs().max())
+    assert e16 < 1e-5 * float(want.abs().max()) and e16 <= 1.5 * ed + 1e-7 * float(want.abs().max()), (e16, ed)
+
+
+@pytest.mark.parametrize("algo", WINO16_ALGOS)
+def test_conv3x3_wino16_full_size_body_conv(ops, dev, algo):
+    """configs[2]'s own body layer: 64 -> 64 @640^2, B = 16 (chip-filling: 14 080 tiles on 256 workgroups, 55 tiles per stream),
+    ReLU + residual; a sub-block of the LAST sample against float64, the whole tensor against the direct f16 x 2 kernel, and
+    bit-identical results across repeated launches."""
+    x = _cl(_rand((16, 64, 640, 640), dev, 470))
+    w, b = _rand((64, 64, 3, 3), dev, 471, 1.0 / 24.0), _rand((64,), dev, 472)
+    r = _cl(_rand((16, 64, 640, 640), dev, 473))
+    got = ops.conv3x3(x, w, b, act=ops.ACT_RELU, res1=r, algo=algo)
+    ref16 = ops.conv3x3(x, w, b, act=ops.ACT_RELU, res1=r, algo="split16")
+    scale = float(ref16.abs().max())
+    assert float((got - ref16).abs().max()) < 1e-5 * scale
+    for rep in range(2):
+        assert torch.equal(ops.conv3x3(x, w, b, act=ops.ACT_RELU, res1=r, algo=algo), got), rep
+    sub = (slice(15, 16), slice(None), slice(570, 640), slice(560, 640))
+    want = (F.conv2d(x[sub].double(), w.double(), b.double(), padding=1).relu() + r[sub].double())[:, :, 2:, 2:]
+    assert float((got[sub][:, :, 2:, 2:].double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("algo", SPLIT_ALGOS)
 def test_conv3x3_split_output_modes(ops, dev, algo):
     """PixelShuffle(2), planar NCHW, ReLU + MaxPool2d(2, 2), a channel-slice source and a strided (bordered) destination."""
