@@ -492,9 +492,12 @@ _SPLIT = _os.environ.get("C2M_CONV_SPLIT", "all")
 # domain |x| < 65520: include/c2m_hip.h C2M_CONV_SPLIT_F16X2); "0" -- the bf16 x 3 flavour (full fp32 range) everywhere.
 # The autograd path (conv3x3_autograd: gradients can be tiny) always runs bf16 x 3.
 _SPLIT16 = _os.environ.get("C2M_CONV_SPLIT16", "1") != "0"
-# C2M_CONV_WINO16: "43" (default) -- where the f16 x 2 flavour would run a channels-last layer with Cout % 64 == 0 it runs behind a
-# Winograd F(4,3) transform ALONG Y (csrc/conv3x3_wino16.hip: half the matrix instructions; same tolerances); "23": F(2,3); "0": off
-_WINO16 = {"43": 7, "23": 8}.get(_os.environ.get("C2M_CONV_WINO16", "43"), 0)
+# C2M_CONV_WINO16: "0" (default) off; "43" / "23" -- where the f16 x 2 flavour would run a channels-last layer with Cout % 64 == 0 it
+# runs behind a Winograd F(4,3) / F(2,3) transform ALONG Y (csrc/conv3x3_wino16.hip: 1/2 / 2/3 of the matrix instructions).  Measured
+# (round 5): F(4,3) is 6 % faster than the direct f16 x 2 kernel on 64 -> 64 @640^2 and 2-2.5x further from float64
+# than the exact-fp32 kernel on 64-channel layers; F(2,3) is more accurate than the direct kernel and 12 % slower -- the family is
+# bound by vector-memory traffic, not by the matrix pipe.  Not the default; algo="wino16" / "wino16_f23" select it per call.
+_WINO16 = {"43": 7, "23": 8}.get(_os.environ.get("C2M_CONV_WINO16", "0"), 0)
 # C2M_DCN_F16X2: "1" (default) -- the DCNv2 forward's implicit GEMM follows the convolutions onto the f16 x 2 arithmetic
 _DCN_F16X2 = _os.environ.get("C2M_DCN_F16X2", "1") != "0"
 # internal kernel ids (= weight-cache kinds; 5 is the data-gradient image of the bf16 x 3 kernel) -> c2m_conv3x3_desc.algo

@@ -98,9 +98,13 @@ __device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
 // compiler otherwise keeps a loop-carried descriptor in vector registers and hands THOSE to the "s" operand).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct RsrcWords { int w0, w1, w2; };
+// (made scalar where they are COMPUTED as well -- under the full exec mask of a uniform call site.  The first hardware run
+// faulted in the re-loads: the words lived in vector registers written inside a lane-masked region of set_source, where lane 0
+// -- halo column x0 - 1, outside the image -- was inactive, and v_readfirstlane at the load picked up lane 0's stale contents.)
 __device__ __forceinline__ RsrcWords rsrc_words(const void* base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)(uintptr_t)base;
-  return RsrcWords{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes};
+  return RsrcWords{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                   __builtin_amdgcn_readfirstlane((int)bytes)};
 }
 __device__ __forceinline__ void buf_load128f(f32x4& d, unsigned voff, const RsrcWords& rw, int soff) {
   i32x4 r;
@@ -109,7 +113,18 @@ __device__ __forceinline__ void buf_load128f(f32x4& d, unsigned voff, const Rsrc
   r[2] = __builtin_amdgcn_readfirstlane(rw.w2);
   r[3] = 0x00020000;
   const int so = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(d) : "v"(voff), "s"(r), "s"(so) : "memory");
+  // s_nop 4: the descriptor words / soffset may come fresh from v_readfirstlane, and the hazard recognizer does not look into an
+  // asm string (VALU writes SGPR -> VMEM reads it: 5 wait states; the second hardware run read a stale num_records word -- the
+  // register had held the weight stream's offset -- and took zeros for every row below it: wrong V_0 on some waves only)
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(d) : "v"(voff), "s"(r), "s"(so) : "memory");
+}
+// The asynchronous loads above are opaque to the compiler: after a wait that covers them, every destination register passes
+// through an empty volatile asm -- a re-definition the scheduler cannot hoist a consumer over (the first hardware run computed the
+// prologue's V_0 from registers whose data had not landed: VALU code moves freely across `asm volatile("s_waitcnt")`).
+template <int N>
+__device__ __forceinline__ void reg_fence(f32x4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
 }
 __device__ __forceinline__ void split2_f16(const f32x4 v, u32x2& p0, u32x2& p1) {
   const f16x4 h0 = __builtin_convertvector(v, f16x4);
@@ -145,6 +160,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
   const int UT = p.nchunks * T;         // units per tile
   const int G = ntl * p.nchunks;        // chunks of this workgroup
   const int NU = G * T;                 // units of this workgroup
+  const int dbg = p.scale;              // bring-up only ($C2M_W16_DBG): 1 no in-loop re-loads, 2 no in-loop items, 4 no in-loop weight DMA
 
   // ---- weights: unit u of this cout block (WUNIT contiguous bytes) -> ring slot u & 3 by LDS-DMA, wave w moves pieces 2w, 2w + 1
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
@@ -188,8 +204,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       const int iy = iy0 - 1 + R * rg + i;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      ivoff[i] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * q) * 4u : kOOB;
+      // pure ALU, no select the compiler could turn into a lane-masked region: an invalid lane's offset gets bit 31 set
+      // (>= any num_records: the hardware returns zeros); valid offsets are < 2^31 (checked by the host)
+      const unsigned bad = ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) ? 1u : 0u;
+      ivoff[i] = ((unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * q) * 4u) | (bad << 31);
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
@@ -209,7 +227,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
       rs = src_rsrc(p.src[1], dma_b);
       set_source(p.src[1]);
     }
-    in_soff = (in_first ? c0 : c0 - p.src[0].C) * 4;
+    in_soff = __builtin_amdgcn_readfirstlane((in_first ? c0 : c0 - p.src[0].C) * 4);
   };
   f32x4 raw[T] = {};   // the lane's halo rows of ONE chunk: fetched in taps T..2T-1 of chunk c-2, transformed in taps 0..T-1 of chunk c-1
   float amax = 0.0f;
@@ -297,21 +315,29 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
       issue_w_done();
     }
   issue_in_begin();
+  __builtin_amdgcn_sched_barrier(0);
   static_for<0, T>([&](auto ic) __attribute__((always_inline)) { load_row(ic); });
   wait_vmcnt<0>();
+  reg_fence(raw);
+  __builtin_amdgcn_sched_barrier(0);
   static_for<0, T>([&](auto tc) __attribute__((always_inline)) { item(tc, 0u); });
+  __builtin_amdgcn_sched_barrier(0);
   if (G > 1) {
     issue_in_begin();
+    __builtin_amdgcn_sched_barrier(0);
     static_for<0, T>([&](auto ic) __attribute__((always_inline)) { load_row(ic); });
   }
   // first operands: A of (unit 0, dx 0), B of (t 0, dx 0) -- after everything above has landed and been published
   wait_vmcnt<0>();
+  reg_fence(raw);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   static_for<0, 2>([&](auto plc) __attribute__((always_inline)) {
     load_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), plc, abase);
     load_b(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), plc, bbase);
   });
+  __builtin_amdgcn_sched_barrier(0);
 
   // ------------------------------------------------------------------------------------------------------------------
   // one chunk = T units of three taps: plane buffer gc & 1 is multiplied; items (taps 0..T-1) transform the registers (chunk
@@ -320,14 +346,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
   unsigned slot = 0;   // ring slot (index) of the current unit
   for (int it = 0, gc = 0; it < ntl; ++it) {
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
-      const bool has_next = gc + 1 < G, more_in = gc + 2 < G;
+      const bool has_next = gc + 1 < G && !(dbg & 2), more_in = gc + 2 < G && !(dbg & 1);
       const unsigned pcur = (unsigned)(gc & 1) * PLB, pnext = PLB - pcur;
       const unsigned bcur = bbase + pcur, bnext = bbase + pnext;
+      reg_fence(raw);   // (the rows fetched during the previous chunk: landed, see the unit-end waits)
       static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         const int u = gc * T + t;
         const unsigned aslot = abase + slot * WUNIT, aslot_n1 = abase + ((slot + 1) & 3) * WUNIT, wslot_n3 = ((slot + 3) & 3) * WUNIT;
-        const bool do_w = u + NRING - 1 < NU;
+        const bool do_w = u + NRING - 1 < NU && !(dbg & 4);
         static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
           constexpr int dx = decltype(dxc)::value, n = 3 * t + dx;
           constexpr int set = n & 1, nset = set ^ 1;
@@ -368,7 +395,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
             }
             // products: g = 0: w1 . x0, g = 1: (2^-11 wA) . x1', g = 2: wA . x0 (smallest terms first)
             const f16x8 av = g == 0 ? A[set][1] : (g == 1 ? Ad : A[set][0]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, Bq[set][g == 1 ? 1 : 0], acc[t], 0, 0, 0);
+            if (!(dbg & 32)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, Bq[set][g == 1 ? 1 : 0], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           });
           if constexpr (dx == 0) {
@@ -381,11 +408,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         constexpr int lo = 3 * t > T ? 3 * t : T, hi_ = 3 * t + 3 < 2 * T ? 3 * t + 3 : 2 * T;
         constexpr int nraw = hi_ > lo ? hi_ - lo : 0;   // re-loads issued in this unit's taps
+        if (!(dbg & 8)) {
         if (do_w && more_in) wait_vmcnt<NW_W + nraw>();
         else if (do_w) wait_vmcnt<NW_W>();
         else if (more_in) wait_vmcnt<nraw>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        }
         slot = (slot + 1) & 3;
       });
     }
@@ -435,7 +464,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int y = y0 + R * rg + r;
-      const bool rok = xok && y < p.H;
+      const bool rok = xok && y < p.H && !((dbg & 16) && r > 0);
       const size_t opix = (size_t)b * p.out_img_pitch + (size_t)(rok ? y : 0) * p.out_row_pitch + (size_t)(rok ? x : 0) * p.out_pix_pitch + co_w;
       f32x4 r1[4], r2[4];
 #pragma unroll
@@ -481,6 +510,8 @@ int launch_wino16(hipStream_t st, Params p, int R) {
   }
   if (env_tpw > 0) tpw = env_tpw;
   p.tpw = (int)tpw;
+  static const int env_dbg = [] { const char* e = getenv("C2M_W16_DBG"); return e ? atoi(e) : 0; }();
+  p.scale = env_dbg;
   dim3 grid((unsigned)((ntile + tpw - 1) / tpw), ncb);
   const size_t ldsb = wino16::lds_bytes(R);
   static unsigned long long done4 = 0, done2 = 0;

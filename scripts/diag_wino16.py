@@ -49,10 +49,13 @@ def run(algo, B, cins, Cout, H, W, act=0, nres=0, R=4):
 
 
 if __name__ == "__main__":
-    f23 = len(sys.argv) > 1 and sys.argv[1] == "f23"
+    f23 = "f23" in sys.argv[1:]
+    only = [int(a) for a in sys.argv[1:] if a.isdigit()]
     algo, R = ("wino16_f23", 2) if f23 else ("wino16", 4)
     ok = True
-    for case in [(1, [16], 64, 16, 30), (1, [16], 64, 8, 32), (1, [64], 64, 16, 30), (1, [64], 64, 40, 40), (2, [64], 64, 37, 45, 1, 2),
-                 (1, [64, 128], 64, 16, 64, 0, 0), (1, [48], 128, 50, 61, 0, 1), (2, [64], 64, 160, 160, 1, 1), (1, [32], 64, 390, 392, 1, 0)]:
+    for k, case in enumerate([(1, [16], 64, 16, 30), (1, [16], 64, 8, 32), (1, [64], 64, 16, 30), (1, [64], 64, 40, 40), (2, [64], 64, 37, 45, 1, 2),
+                 (1, [64, 128], 64, 16, 64, 0, 0), (1, [48], 128, 50, 61, 0, 1), (2, [64], 64, 160, 160, 1, 1), (1, [32], 64, 390, 392, 1, 0)]):
+        if only and k not in only:
+            continue
         ok = run(algo, *case, R=R) and ok
     print("ALL OK" if ok else "FAILURES")
