@@ -657,7 +657,7 @@ def main():
                 want = torch.nn.functional.conv2d(xe.double(), we.double(), be.double(), padding=1)
                 chk = {}   # [max abs, rms] error on a 256 -> 256 layer (K = 2304, outputs ~5)
                 from c2m_amd import ops as _o
-                for name, algo in (("fp32_mfma", "direct"), ("f16x2", "split16"), ("bf16x3", "split")):
+                for name, algo in (("fp32_mfma", "direct"), ("f16x2", "split16"), ("bf16x3", "split"), ("wino16_f43y", "wino16"), ("wino16_f23y", "wino16_f23")):
                     d_ = (_o.conv3x3(xe, we, be, algo=algo).double() - want)
                     chk[name] = [float(f"{float(d_.abs().max()):.3g}"), float(f"{float(d_.pow(2).mean().sqrt()):.3g}")]
                 line["conv_error_vs_fp64"] = chk
@@ -689,6 +689,16 @@ def main():
                     _ops._SPLIT16, _ops._SPLIT = keep
                     with _ops.corr_filter_mode(0):
                         line["value_exact_corr_sweep"] = _rnd(rerun(n_alt), 2)
+                    # round 5's go / no-go on Winograd-along-y over the f16 x 2 pieces (csrc/conv3x3_wino16.hip; opt-in): the same
+                    # step with every eligible channels-last layer on the F(4,3) / F(2,3) kernel
+                    keep_w = _ops._WINO16
+                    try:
+                        _ops._WINO16 = 7
+                        line["value_wino16_f43y_convolutions"] = _rnd(rerun(n_alt), 2)
+                        _ops._WINO16 = 8
+                        line["value_wino16_f23y_convolutions"] = _rnd(rerun(n_alt), 2)
+                    finally:
+                        _ops._WINO16 = keep_w
                 finally:
                     _ops._SPLIT16, _ops._SPLIT = keep
         if world == 1 and not args.no_cpu_baseline and not bf16:

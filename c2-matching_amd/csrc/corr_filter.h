@@ -26,6 +26,7 @@ struct Ws {
   size_t flags;         // int   [8]: [0] != 0 -> the exact sweep must run (inputs outside the filter's domain); [1] work-list length
   size_t keys;          // u64   [B][Hqp*Wqp]: running best (order-preserving value bits, ~index) of queries on the work list
   size_t items;         // {int64 query, int lane, int pad} [SCAN_ITEMS]: whole-lane / whole-map re-score requests
+  size_t maxcol;        // int   [B]: last ref patch column that holds a candidate (everything right of it repeats its left neighbour)
   size_t total;
 };
 
@@ -50,6 +51,7 @@ inline Ws workspace(size_t base, int B, int Hq, int Wq, int Hr, int Wr) {
   w.flags = o; o = al256(o + 32);
   w.keys = o;  o = al256(o + nqp * 8);
   w.items = o; o = al256(o + (size_t)SCAN_ITEMS * 16);
+  w.maxcol = o; o = al256(o + (size_t)B * 4);
   w.total = o;
   return w;
 }
@@ -66,9 +68,11 @@ inline bool shapes_ok(int B, int C, int Hq, int Wq, int Hr, int Wr) {
 // Enqueue: channels-last copies + pieces + candidate scales + bands, the filter sweep, the exact re-score.  On return (in
 // stream order) max_idx / max_val hold the final result unless ws.flags[0] != 0, in which case the caller's exact sweep
 // (which reads the flag on the device) overwrites them.  inv: 1/(|ref patch| + 1e-5) [B][Hrp*Wrp]; ss_in: per-pixel sums of
-// squares of the query map [B][Hq*Wq]; qden: |query patch| + 1e-5 [B][Hqp*Wqp]; skip: the duplicate-row table.
+// squares of the query map [B][Hq*Wq]; qden: |query patch| + 1e-5 [B][Hqp*Wqp]; skip: the duplicate-row table -- UPDATED
+// here: trailing x-tiles without a single candidate (every patch repeats its left / upper neighbour bit for bit: the band a
+// zero-padded Ref leaves on the right) are marked (0, Hr) = "no row swept", for this sweep and for the caller's exact one.
 int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, int Hq, int Wq, int Hr, int Wr, const float* inv,
-           const float* qden, int norm_input, const int2* skip, char* wsbase, const Ws& ws, int64_t* max_idx, float* max_val);
+           const float* qden, int norm_input, int2* skip, char* wsbase, const Ws& ws, int64_t* max_idx, float* max_val);
 
 }  // namespace corrf
 }  // namespace c2m

@@ -168,11 +168,13 @@ __global__ void __launch_bounds__(256) pixel_eq_kernel(const float* __restrict__
 
 // scale of candidate n in the filter: 2^-28 / (|r| + 1e-5), or 0 = "not a candidate" if its patch repeats the patch to its
 // left / above bit for bit
+// maxcol[b] (zeroed by the caller): the last patch column of sample b that holds a candidate
 __global__ void __launch_bounds__(256) cand_scale_kernel(const float* __restrict__ inv, const unsigned char* __restrict__ eq,
                                                           long long npix, int Hr, int Wr, int Hrp, int Wrp,
-                                                          float* __restrict__ sc, int* __restrict__ flags) {
-  const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (n >= Hrp * Wrp) return;
+                                                          float* __restrict__ sc, int* __restrict__ flags, int* __restrict__ maxcol) {
+  const int n0 = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const bool in = n0 < Hrp * Wrp;
+  const int n = in ? n0 : 0;
   const int ry = n / Wrp, rx = n - ry * Wrp;
   const unsigned char* el = eq + (size_t)b * Hr * Wr + (size_t)ry * Wr + rx;
   const unsigned char* eu = el + npix;
@@ -186,8 +188,24 @@ __global__ void __launch_bounds__(256) cand_scale_kernel(const float* __restrict
     }
   const float s = inv[(size_t)b * Hrp * Wrp + n];
   const bool dup = dl || du;   // (eq is 0 in column 0 / row 0: the neighbour patch exists whenever the flags hold)
-  if (!dup && !(s <= INV_CAP && s > 0.0f)) flags[0] = 1;
-  sc[(size_t)b * Hrp * Wrp + n] = dup ? 0.0f : s * SCORE_UNSCALE;
+  if (in) {
+    if (!dup && !(s <= INV_CAP && s > 0.0f)) flags[0] = 1;
+    sc[(size_t)b * Hrp * Wrp + n] = dup ? 0.0f : s * SCORE_UNSCALE;
+  }
+  int mc = (in && !dup) ? rx : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o, 64));
+  if ((threadIdx.x & 63) == 0 && mc > 0) atomicMax(maxcol + b, mc);
+}
+
+// Trailing x-tiles whose every patch is a repeat (first patch column beyond maxcol[b]) are not swept: such a patch ties with a
+// LOWER-indexed one in the filter and in the exact arithmetic alike, it can never be the first maximum (ref_map_util.py:74).
+// Exact and data-dependent like the duplicate-row table it is written into: (0, Hr) = rows [0, Hr) of that (sample, x-tile) skipped.
+__global__ void dead_tiles_kernel(const int* __restrict__ maxcol, int nxt, int n, int Hr, int2* __restrict__ skip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (sample, x-tile)
+  if (i >= n) return;
+  const int b = i / nxt, xt = i - b * nxt;
+  if (xt * WP > maxcol[b]) skip[i] = make_int2(0, Hr);
 }
 
 __global__ void __launch_bounds__(256) band_kernel(const float* __restrict__ qden, long long n, float* __restrict__ band) {
@@ -601,7 +619,7 @@ static int launch_filter_c(hipStream_t st, const _Float16* qpl, const _Float16* 
 }
 
 int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, int Hq, int Wq, int Hr, int Wr, const float* inv,
-           const float* qden, int norm_input, const int2* skip, char* wsbase, const Ws& ws, int64_t* max_idx, float* max_val) {
+           const float* qden, int norm_input, int2* skip, char* wsbase, const Ws& ws, int64_t* max_idx, float* max_val) {
   float* qn = reinterpret_cast<float*>(wsbase + ws.qn);
   float* rn = reinterpret_cast<float*>(wsbase + ws.rn);
   _Float16* qpl = reinterpret_cast<_Float16*>(wsbase + ws.qpl);
@@ -618,7 +636,10 @@ int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, in
   const int nxt = ceil_div(Wrp, WP);
   const long long nqp = (long long)B * Hqp * Wqp, npix_r = (long long)B * HWr;
 
+  int* maxcol = reinterpret_cast<int*>(wsbase + ws.maxcol);
+  static const int dead_tiles = [] { const char* e = getenv("C2M_CORR_DEAD_TILES"); return e ? atoi(e) : 1; }();   // (0: measurement)
   (void)hipMemsetAsync(flags, 0, 32, st);
+  (void)hipMemsetAsync(maxcol, 0, sizeof(int) * (size_t)B, st);
   hipLaunchKernelGGL(to_nhwc_kernel, dim3(ceil_div(HWq, 64), C / 64, B), dim3(256), 0, st, fin, C, HWq, qn);
   hipLaunchKernelGGL(to_nhwc_kernel, dim3(ceil_div(HWr, 64), C / 64, B), dim3(256), 0, st, fref, C, HWr, rn);
   const long long n8 = (long long)B * HWq * (C / 8);
@@ -626,7 +647,8 @@ int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, in
   hipLaunchKernelGGL(split_ref_image_kernel, dim3(Hr, nxt, B), dim3(256), 0, st, rn, C, Hr, Wr, nxt, rimg, flags);
   hipLaunchKernelGGL(pixel_eq_kernel, dim3((unsigned)((npix_r + 3) / 4)), dim3(256), 0, st, rn, C, Hr, Wr, npix_r, eq);
   hipLaunchKernelGGL(cand_scale_kernel, dim3(ceil_div(Hrp * Wrp, 256), B), dim3(256), 0, st, inv, eq, npix_r, Hr, Wr, Hrp, Wrp, sc,
-                     flags);
+                     flags, maxcol);
+  if (dead_tiles) hipLaunchKernelGGL(dead_tiles_kernel, dim3(ceil_div(B * nxt, 64)), dim3(64), 0, st, maxcol, nxt, B * nxt, Hr, skip);
   hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nqp + 255) / 256)), dim3(256), 0, st, qden, nqp, band);
   int rc = check_launch();
   if (rc != C2M_OK) return rc;

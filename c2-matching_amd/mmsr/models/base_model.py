@@ -1,5 +1,6 @@
 """Device placement and data-parallel wrapping for the MI355X path: the changed ``BaseModel.model_to_device``
-(reference: mmsr/models/base_model.py:62-75) plus the save/load helpers that depend on the wrapping (:185-265).
+(reference: mmsr/models/base_model.py:62-75) plus the save/load helpers that depend on the wrapping (:185-265) and the
+training-state save / resume pair (:267-307), so that the file can replace the reference's wholesale.
 
 Why it changed ("DDP on modern PyTorch"): the reference wraps EVERY net in DistributedDataParallel.
 With the installed PyTorch that raises for ``net_map`` (all parameters frozen) and leaves ``net_extractor`` (trainable
@@ -87,3 +88,23 @@ class BaseModel:
         net.load_state_dict(state, strict=strict)
         from c2m_amd import ops as _ops
         _ops.clear_weight_caches()   # (load_state_dict bumps the version counters; this also frees the old images)
+
+    def save_training_state(self, epoch, current_iter):
+        """Optimizer / scheduler states for resuming, written by the master rank only, as `<iter>.state` under
+        opt['path']['training_state'] with the reference's keys (base_model.py:267-290); nothing for current_iter == -1."""
+        if self.rank > 0 or current_iter == -1:
+            return
+        state = {'epoch': epoch, 'iter': current_iter,
+                 'optimizers': [o.state_dict() for o in self.optimizers],
+                 'schedulers': [s.state_dict() for s in self.schedulers]}
+        torch.save(state, os.path.join(self.opt['path']['training_state'], f'{current_iter}.state'))
+
+    def resume_training(self, resume_state):
+        """Reload the optimizers and schedulers from a `.state` dict (base_model.py:292-307; same length checks)."""
+        resume_optimizers, resume_schedulers = resume_state['optimizers'], resume_state['schedulers']
+        assert len(resume_optimizers) == len(self.optimizers), 'Wrong lengths of optimizers'
+        assert len(resume_schedulers) == len(self.schedulers), 'Wrong lengths of schedulers'
+        for o, st in zip(self.optimizers, resume_optimizers):
+            o.load_state_dict(st)
+        for sc, st in zip(self.schedulers, resume_schedulers):
+            sc.load_state_dict(st)

@@ -14,6 +14,8 @@ for stage in "$@"; do
     diag_w16)   (timeout 300 python scripts/diag_wino16.py; timeout 300 python scripts/diag_wino16.py f23) > $O/diag_wino16.log 2>&1 ;;
     bisect_w16) (for m in 0 1 2 4 3 7; do echo "=== C2M_W16_DBG=$m"; C2M_W16_DBG=$m timeout 120 python scripts/diag_wino16.py 0 2 3 2>&1 | grep -v amdgpu.ids | cut -c1-400; done) > $O/bisect_wino16.log 2>&1 ;;
     abl_w16)    (for m in 0 1 2 4 8 16 32 3 19 27 59; do echo "=== C2M_W16_DBG=$m (1 no re-loads, 2 no items, 4 no weight DMA, 8 no unit-end waits/barriers, 16 one output row of four stored, 32 no MFMAs)"; C2M_W16_DBG=$m timeout 120 python scripts/bench_conv.py --algo ${W16_ALGO:-wino16} --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/abl_wino16.log 2>&1 ;;
+    abl128)     (for abl in 0 128; do echo "=== C2M_SPLIT_ABL=$abl (128: the first unit-end wait after a tile's epilogue lets its 16 stores stay in flight)"; C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only "64->64" --iters 20 2>&1 | grep "^{'layer"; done
+                 echo "=== conv tests under C2M_SPLIT_ABL=128"; C2M_SPLIT_ABL=128 timeout 600 python -m pytest tests/test_conv_gpu.py -m gpu -q -x -k "split16 and (fp64 or full_size or scales)" 2>&1 | tail -15) > $O/abl128.log 2>&1 ;;
     test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
     bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;

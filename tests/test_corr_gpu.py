@@ -173,9 +173,15 @@ def test_full_size_160_properties(env, dev):
     fr = oracle.feature_normalize(raw)
     fi[:, 150:, 150:] = fr[:, 130:131, 130:131]   # queries that match the constant band exactly
     ti, tr = _t(fi[None], dev), _t(fr[None], dev)
-    idx, val = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True)
+    idx, val, tab = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True, return_skip=True)
     gidx, gval = ops.feature_match_index_batched(ti, tr, 3, 1, 1, True, True, force_generic=True)
     assert torch.equal(idx, gidx) and torch.equal(val, gval)
+    # round 5: the last x-tile (patch columns 140 .. 157) lies wholly inside the constant band -- every one of its patches
+    # repeats its left neighbour bit for bit and can never be the FIRST maximum -- and is not swept at all: (0, Hr) in the
+    # skip table; x-tile 4 (112 .. 139) still holds candidates and keeps its duplicate-ROW entry
+    tab = tab[0].cpu().numpy()
+    assert tuple(tab[5]) == (0, h), tab
+    assert tab[4][0] > 0 and tab[4][1] == h and all(tuple(tab[k]) == tuple(tab[4]) for k in range(5)), tab
     idx, val = idx[0].cpu().numpy(), val[0].cpu().numpy()
     rows = (0, 2)
     oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True, qrows=rows)

@@ -420,3 +420,42 @@ def test_weight_cache_refresh_follows_writes_through_data():
     assert c.refresh({id(w2)}) == 0
     c.clear()
     assert c.refresh() == 0
+
+
+def test_training_state_round_trips_like_the_reference(tmp_path):
+    """BaseModel.save_training_state / resume_training (mmsr/models/base_model.py:267-307): `<iter>.state` with the keys epoch /
+    iter / optimizers / schedulers, master rank only, nothing for iter -1; resuming restores the Adam moments and the scheduler
+    position and refuses a state with the wrong number of optimizers."""
+    import torch
+    from mmsr.models.base_model import BaseModel
+    opt = {'path': {'training_state': str(tmp_path)}, 'is_train': True}
+
+    def make():
+        m = BaseModel(opt)
+        net = torch.nn.Linear(4, 3)
+        torch.manual_seed(0)
+        o = torch.optim.Adam(net.parameters(), lr=1e-2)
+        m.optimizers.append(o)
+        m.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(o, [2, 5], 0.5))
+        return m, net
+    m, net = make()
+    for _ in range(3):
+        net(torch.ones(2, 4)).sum().backward()
+        m.optimizers[0].step()
+        m.schedulers[0].step()
+    m.save_training_state(epoch=7, current_iter=-1)
+    assert not list(tmp_path.iterdir())
+    m.save_training_state(epoch=7, current_iter=300)
+    state = torch.load(str(tmp_path / '300.state'))
+    assert set(state) == {'epoch', 'iter', 'optimizers', 'schedulers'} and state['epoch'] == 7 and state['iter'] == 300
+    m2, net2 = make()
+    m2.resume_training(state)
+    assert m2.schedulers[0].last_epoch == 3 and m2.optimizers[0].param_groups[0]['lr'] == m.optimizers[0].param_groups[0]['lr']
+    s1, s2 = m.optimizers[0].state_dict()['state'], m2.optimizers[0].state_dict()['state']
+    assert all(torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) and torch.equal(s1[k]['exp_avg_sq'], s2[k]['exp_avg_sq']) for k in s1)
+    m2.optimizers.append(m2.optimizers[0])
+    with pytest.raises(AssertionError, match='Wrong lengths of optimizers'):
+        m2.resume_training(state)
+    m.rank = 1                                     # not the master: nothing is written
+    m.save_training_state(epoch=8, current_iter=400)
+    assert not (tmp_path / '400.state').exists()
