@@ -45,6 +45,7 @@ BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense 
 BF16_SUSTAINED_TFLOPS = 1780.0    # scripts/ubench/mfma_bf16_rate: back-to-back MFMAs on all 1024 SIMDs with non-zero operands
                                   # (the chip clocks down to ~1.7 GHz under that load: profiles/r03_ubench_mfma_bf16_rate.log)
 HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6300.0       # same guide: what a streaming kernel gets
 METRIC = "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)"
 
 
@@ -202,6 +203,13 @@ def conv_rooflines(kern, fam, steps, pmc):
              "traffic": pmc.get(f"{kid}_hbm_bytes_per_step")}
         if kid == "conv3x3_split":
             e["frac_of_sustained_rate"] = _rnd(_tf(execd, kms) / BF16_SUSTAINED_TFLOPS)
+            # the family has TWO roofs: the matrix pipe at the rate it sustains on non-zero operands and HBM at
+            # the ~6.3 TB/s it delivers; `sum` = what a kernel whose memory and matrix phases do not overlap at all would take
+            if e["traffic"]:
+                t_mfma = execd / (BF16_SUSTAINED_TFLOPS * 1e12) * 1e3
+                t_hbm = e["traffic"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+                e["floors_ms"] = {"mfma_at_sustained_rate": _rnd(t_mfma, 1), "hbm_at_6.3TBs": _rnd(t_hbm, 1), "max": _rnd(max(t_mfma, t_hbm), 1),
+                                  "sum": _rnd(t_mfma + t_hbm, 1), "frac_of_max": _rnd(max(t_mfma, t_hbm) / kms)}
         out.append(e)
     return out
 

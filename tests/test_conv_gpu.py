@@ -469,6 +469,7 @@ def test_conv3x3_wino16_domain_and_range_flag(ops, dev, algo):
     recompute on bf16 x 3) -- below it, mixed magnitudes 1e-6 ... 3e3 keep the tolerance; zero weights give exactly the bias."""
     x = _cl(_rand((1, 32, 8, 32), dev, 460))
     w, b = _rand((64, 32, 3, 3), dev, 461, 0.06), _rand((64,), dev, 462)
+    ops.range_flag_set(dev)            # (clear what an earlier test's out-of-domain launch may have reported)
     assert not ops.range_flag_set(dev)
     ops.conv3x3(x, w, b, algo=algo)
     assert not ops.range_flag_set(dev)
