@@ -53,7 +53,7 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
     Hqp, Wqp = (Hq - p) // si + 1, (Wq - p) // si + 1
     L = _lib.lib()
     with torch.cuda.device(fi.device):
-        nbytes = L.c2m_feature_match_workspace_bytes(B, Hq, Wq, Hr, Wr)
+        nbytes = L.c2m_feature_match_workspace_bytes_c(B, C, Hq, Wq, Hr, Wr)   # (sized by the maps' channels: ADVICE r4)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=fi.device)
         idx = torch.empty((B, Hqp, Wqp), dtype=torch.int64, device=fi.device)
         val = torch.empty((B, Hqp, Wqp), dtype=torch.float32, device=fi.device)

@@ -523,7 +523,7 @@ struct CorrWs {
   c2m::corrf::Ws f;   // scratch of the pre-filter path (corr_filter.h)
 };
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
+inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr, int C = c2m::corrf::CMAX) {
   CorrWs w;
   size_t o = 0;
   w.ss_ref = o; o = align256(o + sizeof(float) * (size_t)B * Hr * Wr);
@@ -533,7 +533,7 @@ inline CorrWs corr_ws(int B, int Hq, int Wq, int Hr, int Wr) {
   w.nxt = Wr > 2 ? (Wr - 2 + c2m::corr::WP - 1) / c2m::corr::WP : 1;
   w.row_eq = o; o = align256(o + sizeof(int) * (size_t)B * w.nxt * Hr);
   w.skip = o;   o = align256(o + sizeof(int2) * (size_t)B * w.nxt);
-  w.f = c2m::corrf::workspace(o, B, Hq, Wq, Hr, Wr);
+  w.f = c2m::corrf::workspace(o, B, Hq, Wq, Hr, Wr, C);
   w.total = w.f.total;
   return w;
 }
@@ -599,6 +599,14 @@ extern "C" size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int H
   return corr_ws(B, Hq, Wq, Hr, Wr).total;
 }
 
+// channels the pre-filter's per-channel scratch is laid out for: C where the filter has a kernel, else none
+static int filter_channels(int C) { return (C == 64 || C == 128 || C == 256) ? C : 0; }
+
+extern "C" size_t c2m_feature_match_workspace_bytes_c(int B, int C, int Hq, int Wq, int Hr, int Wr) {
+  if (B <= 0 || C <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0) return 0;
+  return corr_ws(B, Hq, Wq, Hr, Wr, filter_channels(C)).total;
+}
+
 extern "C" int c2m_feature_match_skip_table(int B, int Hq, int Wq, int Hr, int Wr, size_t* byte_offset, int* x_tiles) {
   if (B <= 0 || Hq <= 0 || Wq <= 0 || Hr <= 0 || Wr <= 0 || !byte_offset || !x_tiles) return C2M_ERR_INVALID_ARG;
   const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr);
@@ -615,7 +623,7 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
   if (!feat_in || !feat_ref || !max_idx || !max_val) return C2M_ERR_INVALID_ARG;
   if (B <= 0 || C <= 0 || patch <= 0 || in_stride <= 0 || ref_stride <= 0) return C2M_ERR_INVALID_ARG;
   if (Hq < patch || Wq < patch || Hr < patch || Wr < patch) return C2M_ERR_INVALID_ARG;
-  const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr);
+  const CorrWs ws = corr_ws(B, Hq, Wq, Hr, Wr, filter_channels(C));   // (<= what either size query returns)
   if (!workspace || workspace_bytes < ws.total) return C2M_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   char* wsb = static_cast<char*>(workspace);

@@ -32,17 +32,16 @@ struct Ws {
 
 inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
 
-inline Ws workspace(size_t base, int B, int Hq, int Wq, int Hr, int Wr) {
+// C: channels the maps have (CMAX = an upper bound for callers that do not know; 0 = the filter cannot run on these maps: no
+// per-channel scratch at all).  The C-INDEPENDENT tables come first, so that their offsets -- what the diagnostics entry points
+// report -- do not depend on C; the per-channel blocks follow.
+inline Ws workspace(size_t base, int B, int Hq, int Wq, int Hr, int Wr, int C = CMAX) {
   Ws w;
   size_t o = al256(base);
   const size_t nq = (size_t)B * Hq * Wq, nr = (size_t)B * Hr * Wr;
   const size_t nqp = (size_t)B * (Hq > 2 ? Hq - 2 : 1) * (Wq > 2 ? Wq - 2 : 1);
   const size_t nrp = (size_t)B * (Hr > 2 ? Hr - 2 : 1) * (Wr > 2 ? Wr - 2 : 1);
   const size_t nxt = Wr > 2 ? (size_t)(Wr - 2 + WP - 1) / WP : 1;
-  w.qn = o;    o = al256(o + nq * CMAX * 4);
-  w.rn = o;    o = al256(o + nr * CMAX * 4);
-  w.qpl = o;   o = al256(o + nq * CMAX * 4);
-  w.rimg = o;  o = al256(o + (size_t)B * nxt * Hr * CMAX * 128);
   w.sb = o;    o = al256(o + nrp * 8);
   w.band = o;  o = al256(o + nqp * 4);
   w.eq = o;    o = al256(o + 2 * nr);
@@ -52,6 +51,11 @@ inline Ws workspace(size_t base, int B, int Hq, int Wq, int Hr, int Wr) {
   w.keys = o;  o = al256(o + nqp * 8);
   w.items = o; o = al256(o + (size_t)SCAN_ITEMS * 16);
   w.maxcol = o; o = al256(o + (size_t)B * 4);
+  const size_t c = (size_t)(C < 0 ? 0 : C);
+  w.qn = o;    o = al256(o + nq * c * 4);
+  w.rn = o;    o = al256(o + nr * c * 4);
+  w.qpl = o;   o = al256(o + nq * c * 4);
+  w.rimg = o;  o = al256(o + (size_t)B * nxt * Hr * c * 128);
   w.total = o;
   return w;
 }

@@ -129,6 +129,7 @@ class RefRestorationModel(BaseModel):
         their addresses: each replay rewrites them in place."""
         if self._graph is not None:
             self._graph.replay()
+            self.output = self._graph_output   # (a validation in between re-pointed / deleted the attribute: ADVICE r4)
             return
         self._graph_calls += 1
         cur = torch.cuda.current_stream()
@@ -144,6 +145,7 @@ class RefRestorationModel(BaseModel):
         with torch.cuda.graph(graph):
             self._train_step()
         self._graph = graph
+        self._graph_output = self.output       # the tensor every replay rewrites in place
         graph.replay()
 
     # ---------------------------------------------------------------- validation

@@ -74,6 +74,10 @@ int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C,
 /* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps, duplicate-row table, and
  * the pre-filter's channels-last copies / f16 pieces / candidate lists, sized for C = 256). */
 size_t c2m_feature_match_workspace_bytes(int B, int Hq, int Wq, int Hr, int Wr);
+/* The same for maps of C channels: the pre-filter's per-channel scratch is sized by C (none where the filter has no kernel:
+ * C other than 64 / 128 / 256) instead of the 256-channel upper bound -- a quarter of the bytes at C = 64, a few MB where only
+ * the generic kernel can run.  c2m_feature_match_index_f32 accepts a workspace of either size. */
+size_t c2m_feature_match_workspace_bytes_c(int B, int C, int Hq, int Wq, int Hr, int Wr);
 
 /*
  * Diagnostics for the MFMA kernel's duplicate-row elimination: after c2m_feature_match_index_f32 the workspace holds,

@@ -47,3 +47,18 @@ def test_cpu_tensors_are_rejected_not_emulated():
         c2m_amd.ops.feature_match_index_batched(torch.zeros(1, 4, 8, 8), torch.zeros(1, 4, 8, 8))
     with pytest.raises(c2m_amd.C2MError):
         c2m_amd.ops.dcn_v2_forward(torch.zeros(1, 4, 5, 5), torch.zeros(2, 4, 3, 3), torch.zeros(2), torch.zeros(1, 18, 5, 5), torch.zeros(1, 9, 5, 5))
+
+
+def test_correlation_workspace_is_sized_by_the_maps_channels():
+    """the pre-filter's per-channel scratch follows C (none where the filter has no kernel); the C-less query keeps
+    returning the 256-channel upper bound, which every layout fits (no GPU needed: pure size arithmetic in the library)."""
+    import c2m_amd
+    L = c2m_amd._lib.lib()
+    shp = (16, 160, 160, 160, 160)
+    upper = L.c2m_feature_match_workspace_bytes(*shp)
+    by_c = {c: L.c2m_feature_match_workspace_bytes_c(shp[0], c, *shp[1:]) for c in (32, 64, 128, 256)}
+    assert by_c[256] == upper and by_c[64] < by_c[128] < by_c[256]
+    assert by_c[32] < 64 << 20 < by_c[64]                 # no filter kernel for C = 32: tables only
+    per_c = (by_c[256] - by_c[128]) / 128                 # bytes per channel of the four per-channel blocks
+    assert abs((by_c[128] - by_c[64]) / 64 - per_c) <= 1024 and abs(by_c[64] - by_c[32] - 64 * per_c) <= 4096
+    assert L.c2m_feature_match_workspace_bytes_c(0, 256, 160, 160, 160, 160) == 0

@@ -626,6 +626,13 @@ def test_hip_graph_training_step_matches_the_eager_step(dev):
         assert graphed._graph is not None and bool(torch.isfinite(graphed.log_dict["l_g_pix"]))
         sr = graphed.test()                                         # the fused inference path still runs beside the graph
         assert bool(torch.isfinite(sr).all())
+        # ... and a validation between two replays (test() re-points `output`, the reference's loop then deletes it) leaves the
+        # next replay's result where the trainer looks for it: `output` is the captured step's tensor again
+        captured = graphed._graph_output
+        del graphed.output
+        graphed.optimize_parameters(11)
+        torch.cuda.synchronize()
+        assert graphed.output is captured and graphed.output.requires_grad and bool(torch.isfinite(graphed.output).all())
     finally:
         arch._TRAIN_KERNELS = "auto"
 
