@@ -93,6 +93,21 @@ for stage in "$@"; do
                 cd $R
                 (python scripts/pmc_kernel.py $O/pmc5_fetch c2m; python scripts/pmc_kernel.py $O/pmc5_write c2m) > $O/pmc_cfg5_summary.txt 2>&1
                 rm -rf $O/pmc5_fetch $O/pmc5_write ;;
+    prof_train) cd /tmp
+                timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_train -o t -- python $R/bench.py --workload train --batch 4 --steps 10 --warmup 3 > $O/rocprof_train.log 2>&1
+                cd $R
+                python - "$O" <<'PY'
+import csv, sys, glob
+O = sys.argv[1]
+f = glob.glob(O + "/prof_train/**/t_kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0]))) if f else []
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(O + "/train_b4_kernel_stats.txt", "w") as out:
+    out.write("total kernel ms over 13 steps: %.1f, kernels: %d kinds, launches %d\n" % (tot / 1e6, len(rows), sum(int(r["Calls"]) for r in rows)))
+    for r in rows[:45]:
+        out.write("%-100s calls %6s total_ms %9.3f avg_us %9.2f pct %s\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+                rm -rf $O/prof_train ;;
     pmc_train)  cd /tmp
                 for c in FETCH_SIZE WRITE_SIZE; do   # (one counter per pass: both together exceed what the hardware collects)
                   timeout 400 rocprofv3 --pmc $c --kernel-trace -f csv -d $O/pmct_$c -o s -- python $R/bench.py --workload train --global-batch 4 --steps 3 --warmup 2 > $O/pmct_$c.log 2>&1
