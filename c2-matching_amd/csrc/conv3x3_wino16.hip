@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino16_kernel(Params p) {
           if constexpr (n == T) {
             if (more_in) issue_in_begin();   // (the chunk the re-loads of taps T..2T-1 fetch)
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (!(dbg & 64)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           static_for<0, 3>([&](auto gcnt) __attribute__((always_inline)) {
             constexpr int g = decltype(gcnt)::value;

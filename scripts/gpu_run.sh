@@ -13,9 +13,20 @@ for stage in "$@"; do
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ;;
     diag_w16)   (timeout 300 python scripts/diag_wino16.py; timeout 300 python scripts/diag_wino16.py f23) > $O/diag_wino16.log 2>&1 ;;
     bisect_w16) (for m in 0 1 2 4 3 7; do echo "=== C2M_W16_DBG=$m"; C2M_W16_DBG=$m timeout 120 python scripts/diag_wino16.py 0 2 3 2>&1 | grep -v amdgpu.ids | cut -c1-400; done) > $O/bisect_wino16.log 2>&1 ;;
-    abl_w16)    (for m in 0 1 2 4 8 16 32 3 19 27 59; do echo "=== C2M_W16_DBG=$m (1 no re-loads, 2 no items, 4 no weight DMA, 8 no unit-end waits/barriers, 16 one output row of four stored, 32 no MFMAs)"; C2M_W16_DBG=$m timeout 120 python scripts/bench_conv.py --algo ${W16_ALGO:-wino16} --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/abl_wino16.log 2>&1 ;;
+    abl_w16)    (for m in ${W16_MASKS:-0 1 2 4 8 16 32 64 3 19 27 59 72 123}; do echo "=== C2M_W16_DBG=$m (1 no re-loads, 2 no items, 4 no weight DMA, 8 no unit-end waits/barriers, 16 one output row of four stored, 32 no MFMAs)"; C2M_W16_DBG=$m timeout 120 python scripts/bench_conv.py --algo ${W16_ALGO:-wino16} --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/abl_wino16.log 2>&1 ;;
     abl128)     (for abl in 0 128; do echo "=== C2M_SPLIT_ABL=$abl (128: the first unit-end wait after a tile's epilogue lets its 16 stores stay in flight)"; C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only "64->64" --iters 20 2>&1 | grep "^{'layer"; done
                  echo "=== conv tests under C2M_SPLIT_ABL=128"; C2M_SPLIT_ABL=128 timeout 600 python -m pytest tests/test_conv_gpu.py -m gpu -q -x -k "split16 and (fp64 or full_size or scales)" 2>&1 | tail -15) > $O/abl128.log 2>&1 ;;
+    pmc_w16)    cd /tmp
+                for a in split16 wino16 wino16_f23; do
+                  timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace -f csv -d $O/pmcw_$a -o c -- python $R/scripts/bench_conv.py --algo $a --only 'body 64->64 @640' --iters 6 > $O/pmcw_$a.log 2>&1
+                  echo "=== --algo $a" >> $O/pmc_wino16.txt
+                  grep "^{'layer" $O/pmcw_$a.log >> $O/pmc_wino16.txt
+                  python $R/scripts/pmc_kernel.py $O/pmcw_$a conv3x3_ >> $O/pmc_wino16.txt 2>&1
+                  timeout 200 rocprofv3 --pmc SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS --kernel-trace -f csv -d $O/pmcx_$a -o c -- python $R/scripts/bench_conv.py --algo $a --only 'body 64->64 @640' --iters 6 > $O/pmcx_$a.log 2>&1
+                  python $R/scripts/pmc_kernel.py $O/pmcx_$a conv3x3_ >> $O/pmc_wino16.txt 2>&1
+                  rm -rf $O/pmcw_$a $O/pmcx_$a
+                done
+                cd $R ;;
     test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
     bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
