@@ -12,9 +12,13 @@
 //   y[R] = A^T ( (G g) . (B^T d) ),  per pixel column and channel pair;  B^T is applied in fp32 BEFORE the f16 split
 //   (B^T/4 for R = 4: exact scaling, keeps |V| <= 2.5 max|d|), G in float64 before the weight split (4 G for R = 4),
 //   the products are the three f16 x 2 products of conv3x3_split.hip (wA.x0 + w1.x0 + 2^-11 wA.x1'), A^T in fp32.
-// Error against float64: BELOW the direct f16 x 2 kernel's for R = 2 and at the exact-fp32-MFMA chain's level for R = 4
-// (each transform-domain accumulator sums a third / a ninth of the products of a direct accumulator; measured in
-// tests/test_conv_gpu.py, predicted by scripts/sim_wino16_numerics.py before the kernel was written).
+// Error against float64, measured (tests/test_conv_gpu.py, bench.py's conv_error_vs_fp64; modelled beforehand by
+// scripts/sim_wino16_numerics.py): R = 2 BELOW the direct f16 x 2 kernel's (each transform-domain accumulator sums a third of
+// the products of a direct one); R = 4 inside 1e-5 * scale but 1.6 x (K = 2304) to 2.5 x (K = 576) the exact-fp32-MFMA kernel's.
+// STATUS (round 5): opt-in ($C2M_CONV_WINO16, algo = C2M_CONV_WINO_F16X2_F43Y / _F23Y).  On the 64 -> 64 @640^2
+// layer F(4,3) is 6 % faster than the direct kernel, F(2,3) 13 % slower: with half the MFMAs the chip clocks 28 % higher, but
+// this mapping needs 24 % more cycles (MFMA busy 0.25; waves parked 44 % of their cycles) -- the family is bound by vector-memory
+// traffic and its own control flow, not by the matrix pipe.  $C2M_W16_DBG: timing-only ablation mask (wrong results).
 //
 // Mapping: one workgroup = 8 waves, two per SIMD, ONE workgroup per CU; tile = 30 x 4R output pixels x 64 couts:
 //   * wave w owns output rows [R g, R g + R) of the tile, g = w >> 1, and cout tile mt = w & 1: accumulators acc[t], t = 0 .. R+1
