@@ -319,6 +319,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // PIPE: two plane buffers -- the split of chunk c+1 is interleaved with the MFMAs of chunk c (no phase (A), no barrier for
   // it).  The bf16 x 3 flavour keeps one buffer and phase (A): two of its workgroups would not fit a CU otherwise.
   constexpr bool PIPE = FL != 3;
+  // BF (round 5): the chunk loop of the pipelined fp32-tensor flavours runs WITHOUT uniform branches around its asynchronous
+  // issues: past the end of the workgroup's stream the weight pieces land in the dummy page, the halo loads go through a
+  // descriptor of zero records (no memory traffic, zeros into dead registers) and the split rounds write a plane buffer nobody
+  // reads -- so every unit issues exactly the same vector-memory instructions and its end waits with ONE constant count.
+  // (38 branches per 108 MFMAs before; the wino16 counters showed what scalar control flow costs eight waves per CU.)
+#ifndef C2M_SPLIT_BF
+#define C2M_SPLIT_BF 1
+#endif
+  constexpr bool BF = PIPE && !IO16 && ABL == 0 && C2M_SPLIT_BF != 0;
   constexpr int NPB = IO16 ? 3 : (PIPE ? 2 : 1);
   constexpr int NRING = PIPE ? 3 : 2;           // weight ring slots; unit u's weights are issued NRING-1 units ahead
   constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
@@ -346,15 +355,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.wr) + (size_t)cb * UT * WUNIT, (unsigned)UT * WUNIT);
   const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
   int wsoff = 0;   // unit the NEXT issue fetches (wraps per tile)
-  auto issue_w_piece = [&](unsigned slot_off, int i) __attribute__((always_inline)) {
+  auto issue_w_piece = [&](unsigned slot_off, int i, bool live = true) __attribute__((always_inline)) {
     const int n = wv * NW_W + i;
-    const unsigned dst = n < NWI ? w_base + slot_off + n * 1024 : dummy;
+    const unsigned dst = (n < NWI && live) ? w_base + slot_off + n * 1024 : dummy;
     // (beyond the image: reads the next unit / zeros past the end of the buffer, lands in the dummy page)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff + i * 1024, 0, 0);
   };
-  auto issue_w_done = [&]() __attribute__((always_inline)) {
-    wsoff += WUNIT;
-    if (wsoff == UT * WUNIT) wsoff = 0;
+  auto issue_w_done = [&](bool live = true) __attribute__((always_inline)) {
+    const int nx = wsoff + WUNIT == UT * WUNIT ? 0 : wsoff + WUNIT;
+    wsoff = live ? nx : wsoff;
   };
 
   // ---- halo tile: 24 slots of 64 pieces (pixel, 4 fp32 channels); slot r of wave wv = pieces [64 (wv + 4r), +64), fetched
@@ -447,10 +456,22 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                                              dvoff[sl], in_soff, 0, 0);
   };
   f32x4 rawr[NRAW_W];
+  i32x4 rs_cur = {0, 0, 0, 0x00020000};   // BF: descriptor of the chunk being fetched (set_chunk_rsrc)
+  auto set_chunk_rsrc = [&](bool live) __attribute__((always_inline)) {
+    const i32x4 r = in_first ? rs0 : rs1;
+    rs_cur[0] = r[0];
+    rs_cur[1] = r[1];
+    rs_cur[2] = live ? r[2] : 0;        // zero records: every lane out of range -> zeros, no memory traffic
+    rs_cur[3] = 0x00020000;
+  };
   auto issue_in_piece = [&](auto slc) __attribute__((always_inline)) {
     constexpr int sl = decltype(slc)::value;
-    if (in_first) buf_load128f(rawr[sl], ivoff[sl], rs0, in_soff);
-    else buf_load128f(rawr[sl], ivoff[sl], rs1, in_soff);
+    if constexpr (BF) {
+      buf_load128f(rawr[sl], ivoff[sl], rs_cur, in_soff);
+    } else {
+      if (in_first) buf_load128f(rawr[sl], ivoff[sl], rs0, in_soff);
+      else buf_load128f(rawr[sl], ivoff[sl], rs1, in_soff);
+    }
   };
 
   // ---- split of the wave's own raw pieces into the bf16 planes.  Round r: piece 64 (wv + 4r) + l = (pixel 16 (wv + 4r) +
@@ -526,6 +547,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) issue_in_dma(sl, 0u);
   } else {
+    if constexpr (BF) set_chunk_rsrc(true);
     static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
   }
 #pragma unroll
@@ -552,6 +574,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   if constexpr (PIPE && !IO16) {   // chunk 0 -> plane buffer 0; the registers re-load with chunk 1
     const bool more1 = !(ABL & 2) && G > 1;
     if (more1) issue_in_begin();
+    if constexpr (BF) set_chunk_rsrc(more1);
     static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
       constexpr int R = decltype(rr)::value;
       conv_split(rawr[R]);
@@ -588,6 +611,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       const unsigned pb_in = (unsigned)((gc + 2) % 3) * PLB;   // IO16: where chunk gc+2 lands
       const unsigned bcur = bbase + pb, cnext = PIPE ? cdst + (PLB - pb) : cdst;
       if (more_in) issue_in_begin();
+      if constexpr (BF) set_chunk_rsrc(more_in);
       if constexpr (!PIPE) {
         // ---- (A) split
         if constexpr (!(ABL & 4)) {
@@ -640,9 +664,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               });
             }
             if constexpr (dx == 0) {
-              if (do_w) {
+              if constexpr (BF) {
 #pragma unroll
-                for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i);
+                for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i, do_w);
+              } else {
+                if (do_w) {
+#pragma unroll
+                  for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i);
+                }
               }
             }
             if constexpr (FL == 2 && g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
@@ -658,13 +687,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             }
             if constexpr (PIPE && !IO16 && dx >= 1 && g == NG / 2 && !(ABL & 4)) {   // split round R of the next chunk
               constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
-              if (has_next) {
+              if (BF || has_next) {
                 if constexpr (dy == 0) {
                   if (gc == 0) wait_vmcnt<0>();   // (chunk 1's raw pieces were issued by the prologue: no unit end since)
                 }
                 conv_split(rawr[R]);
                 conv_store(std::integral_constant<int, R>(), cnext);
-                if (more_in) issue_in_piece(std::integral_constant<int, R>());
+                if (BF || more_in) issue_in_piece(std::integral_constant<int, R>());
               }
             }
             if constexpr (!(ABL & 16) && !((ABL & 256) && dx == 2)) {   // (256: only two of the three taps' MFMAs -- what a Winograd F(2,3) would issue)
@@ -684,14 +713,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             __builtin_amdgcn_sched_barrier(0);
           });
           if constexpr (dx == 0) {
-            if (do_w) issue_w_done();
+            if constexpr (BF) issue_w_done(do_w);
+            else if (do_w) issue_w_done();
           }
         });
         if (!(ABL & 8)) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           // PIPE, steady state: the weights of unit u+1 (issued in unit u-1) landed, and with them every raw load older than
           // unit u-1's; still in flight may be: raw(u-1) x 2, W(u+2) x NW_W, raw(u) x 2.  (vmcnt counts in issue order.)
-          if (IO16 && more_in) {
+          if constexpr (BF) {
+            wait_vmcnt<4 + NW_W>();   // (every unit issued its NW_W pieces and two loads, live or not: one constant count)
+          } else if (IO16 && more_in) {
             wait_vmcnt<2 + NW_W>();   // in flight may be: halo piece of unit u-1, W(u+2) x NW_W, halo piece of unit u
           } else if (PIPE && !IO16 && more_in) {
             if ((ABL & 128) && c == 0 && dy == 0) wait_vmcnt<4 + NW_W + 16>();
