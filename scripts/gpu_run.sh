@@ -27,9 +27,9 @@ for stage in "$@"; do
                   rm -rf $O/pmcw_$a $O/pmcx_$a
                 done
                 cd $R ;;
-    ab_bf)      (for lib in "" $R/build_exp/libc2m_base.so "" $R/build_exp/libc2m_base.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_branch_free.log 2>&1
+    ab_bf)      (for lib in "" $R/build_exp/${AB_LIB:-libc2m_base.so} "" $R/build_exp/${AB_LIB:-libc2m_base.so}; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_branch_free.log 2>&1
                 (echo "=== in-tree (branch-free chunk loop)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600
-                 echo "=== C2M_LIB=build_exp/libc2m_base.so"; C2M_LIB=$R/build_exp/libc2m_base.so timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600) > $O/ab_branch_free_step.log 2>&1 ;;
+                 echo "=== C2M_LIB=build_exp/${AB_LIB:-libc2m_base.so}"; C2M_LIB=$R/build_exp/${AB_LIB:-libc2m_base.so} timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600) > $O/ab_branch_free_step.log 2>&1 ;;
     test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
     bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
