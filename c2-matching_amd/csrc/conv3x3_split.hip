@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #ifndef C2M_SPLIT_BF
 #define C2M_SPLIT_BF 1
 #endif
-  constexpr bool BF = PIPE && !IO16 && ABL == 0 && C2M_SPLIT_BF != 0;
+  constexpr bool BFA = ABL == 0 && C2M_SPLIT_BF != 0;   // any flavour: weight pieces / unit-end waits without branches
+  constexpr bool BF = BFA && !IO16;                     // register-loaded halo tiles (fp32 sources)
+  constexpr bool BF16S = BFA && IO16;                   // LDS-DMA halo tiles (bf16 sources)
   constexpr int NPB = IO16 ? 3 : (PIPE ? 2 : 1);
   constexpr int NRING = PIPE ? 3 : 2;           // weight ring slots; unit u's weights are issued NRING-1 units ahead
   constexpr int WTAP = NPW * MT * 1024;         // one tap's weight image: [image][mt][half][32 rows][16 B]
@@ -404,8 +406,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       const int pid = 64 * (wv + 4 * sl) + l, kh = pid >= NPIX ? 1 : 0, pix = pid - kh * NPIX;
       const int ry = pix / HWc, rx = pix - ry * HWc;
       const int iy = iy0 - 1 + ry, ix = ix0 - 1 + rx;
-      const bool ok = pid < 2 * NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      dvoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 8 * kh) * 2u : kOOB;
+      // (pure ALU -- an invalid lane's offset gets bit 31 set, i.e. lies beyond any num_records -- instead of a select that
+      // the compiler turns into a lane-masked region per piece; valid offsets are < 2^31: checked by the host)
+      const unsigned bad = (pid < 2 * NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? 0u : 1u;
+      dvoff[sl] = ((unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 8 * kh) * 2u) | (bad << 31);
     }
   };
   auto set_source = [&](const Src& S) __attribute__((always_inline)) {
@@ -413,8 +417,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     for (int sl = 0; sl < NRAW_W; ++sl) {
       const int c = slotc[sl];
       const int iy = iy0 - 1 + (c & 0xff), ix = ix0 - 1 + ((c >> 8) & 0xff);
-      const bool ok = (c >> 24) != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      ivoff[sl] = ok ? (unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * ((c >> 16) & 3)) * 4u : kOOB;
+      const unsigned bad = ((c >> 24) != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? 0u : 1u;
+      ivoff[sl] = ((unsigned)(iy * S.row_pitch + ix * S.pix_pitch + 4 * ((c >> 16) & 3)) * 4u) | (bad << 31);   // (as set_source16)
     }
   };
   auto src_rsrc = [&](const Src& S, int b) __attribute__((always_inline)) {
@@ -451,8 +455,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     in_soff = (in_first ? c0 : c0 - p.src[0].C) * 4;
   };
   // IO16: piece `sl` of the chunk issue_in_begin() has just set up -> plane buffer at byte offset `plane_off`
+  __amdgpu_buffer_rsrc_t in_rs16_cur = in_rs16;   // BF16S: in_rs16, or a descriptor of zero records past the stream's end
+  const __amdgpu_buffer_rsrc_t null_rs16 = make_rsrc(p.src[0].ptr, 0u);
   auto issue_in_dma = [&](int sl, unsigned plane_off) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs16, (__attribute__((address_space(3))) void*)(pl_base + plane_off + (unsigned)(wv + 4 * sl) * 1024u), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(BF16S ? in_rs16_cur : in_rs16, (__attribute__((address_space(3))) void*)(pl_base + plane_off + (unsigned)(wv + 4 * sl) * 1024u), 16,
                                              dvoff[sl], in_soff, 0, 0);
   };
   f32x4 rawr[NRAW_W];
@@ -544,6 +550,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   // ------------------------------------------------------------------------------------------------------------------
   issue_in_begin();
   if constexpr (IO16) {
+    in_rs16_cur = in_rs16;
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) issue_in_dma(sl, 0u);
   } else {
@@ -563,6 +570,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   if constexpr (IO16) {   // chunk 1 -> plane buffer 1; both landed and published before the first unit
     if (G > 1) {
       issue_in_begin();
+      in_rs16_cur = in_rs16;
 #pragma unroll
       for (int sl = 0; sl < 3; ++sl) issue_in_dma(sl, (unsigned)PLB);
     }
@@ -612,6 +620,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       const unsigned bcur = bbase + pb, cnext = PIPE ? cdst + (PLB - pb) : cdst;
       if (more_in) issue_in_begin();
       if constexpr (BF) set_chunk_rsrc(more_in);
+      if constexpr (BF16S) in_rs16_cur = more_in ? in_rs16 : null_rs16;
       if constexpr (!PIPE) {
         // ---- (A) split
         if constexpr (!(ABL & 4)) {
@@ -619,7 +628,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             constexpr int R = decltype(rr)::value;
             conv_split(rawr[R]);
             conv_store(rr, cdst);
-            if (more_in) issue_in_piece(rr);    // same slot of the next chunk
+            if (BF || more_in) issue_in_piece(rr);    // same slot of the next chunk
           });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -664,7 +673,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               });
             }
             if constexpr (dx == 0) {
-              if constexpr (BF) {
+              if constexpr (BFA) {
 #pragma unroll
                 for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i, do_w);
               } else {
@@ -683,7 +692,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               }
             }
             if constexpr (IO16 && dx == 1 && g == NG / 2) {   // halo piece dy of chunk gc+2 (one per unit)
-              if (more_in) issue_in_dma(dy, pb_in);
+              if (BF16S || more_in) issue_in_dma(dy, pb_in);
             }
             if constexpr (PIPE && !IO16 && dx >= 1 && g == NG / 2 && !(ABL & 4)) {   // split round R of the next chunk
               constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
@@ -713,7 +722,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             __builtin_amdgcn_sched_barrier(0);
           });
           if constexpr (dx == 0) {
-            if constexpr (BF) issue_w_done(do_w);
+            if constexpr (BFA) issue_w_done(do_w);
             else if (do_w) issue_w_done();
           }
         });
@@ -721,8 +730,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           // PIPE, steady state: the weights of unit u+1 (issued in unit u-1) landed, and with them every raw load older than
           // unit u-1's; still in flight may be: raw(u-1) x 2, W(u+2) x NW_W, raw(u) x 2.  (vmcnt counts in issue order.)
-          if constexpr (BF) {
+          if constexpr (BF && PIPE) {
             wait_vmcnt<4 + NW_W>();   // (every unit issued its NW_W pieces and two loads, live or not: one constant count)
+          } else if constexpr (BF16S) {
+            wait_vmcnt<2 + NW_W>();   // (likewise: NW_W pieces and one halo piece per unit)
           } else if (IO16 && more_in) {
             wait_vmcnt<2 + NW_W>();   // in flight may be: halo piece of unit u-1, W(u+2) x NW_W, halo piece of unit u
           } else if (PIPE && !IO16 && more_in) {
