@@ -226,6 +226,13 @@ __device__ __forceinline__ unsigned select_u32(unsigned long long lane_mask, uns
   return r;
 }
 
+// C2M_CORRF_ABL (compile-time, measurement builds only -- results are wrong with any bit set; scripts/abl_corr_filter.py):
+// 1 B operands read once per row and reused, 2 no ring reads in the tap rounds, 4 no tap rounds, 8 no row-sum tail (DPP + ring
+// stores), 16 no MFMAs.  Round 5, C = 256, 160 x 160 maps, B = 16, no skipped rows: 25.2 ms; 1: 24.1, 2: 23.6, 3: 22.5, 4: 20.9,
+// 8: 24.3, 15 (MFMAs + row DMA + barriers only): 18.7 = the pipe at the 1.42 GHz the chip holds under it; 16: 10.6.
+#ifndef C2M_CORRF_ABL
+#define C2M_CORRF_ABL 0
+#endif
 template <int C, int PF>
 __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     const _Float16* __restrict__ qpl, const _Float16* __restrict__ rimg, int Hq, int Wq, int Hr, int Wr, int tiles_y, int tiles_x,
@@ -346,21 +353,26 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     hq[0] = a0[0]; hq[1] = a1[0]; hq[2] = a2[0];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[1][t], b0[t % (PF + 1)], acc, 0, 0, 0);   // smallest terms first
+      if (!(C2M_CORRF_ABL & 16)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[1][t], b0[t % (PF + 1)], acc, 0, 0, 0);   // smallest terms first
       __builtin_amdgcn_sched_barrier(0);
-      if (t + PF < KS) {
+      if ((C2M_CORRF_ABL & 1) && t + PF < KS) {
+        b0[(t + PF) % (PF + 1)] = b0[t % (PF + 1)];
+        b1[(t + PF) % (PF + 1)] = b1[t % (PF + 1)];
+      } else if (t + PF < KS) {
         b0[(t + PF) % (PF + 1)] = *reinterpret_cast<const f16x8*>(bsrc + (t + PF) * 1024);
         b1[(t + PF) % (PF + 1)] = *reinterpret_cast<const f16x8*>(bsrc + (KS + t + PF) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b1[t % (PF + 1)], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b0[t % (PF + 1)], acc, 0, 0, 0);
+      if (!(C2M_CORRF_ABL & 16)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b1[t % (PF + 1)], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[0][t], b0[t % (PF + 1)], acc, 0, 0, 0);
+      }
       // tap-sum rounds [t NIT / KS, (t+1) NIT / KS)
 #pragma unroll
-      for (int r = t * NIT / KS; r < (t + 1) * NIT / KS; ++r) {
+      for (int r = (C2M_CORRF_ABL & 4) ? NIT : t * NIT / KS; r < (t + 1) * NIT / KS; ++r) {
         float sum = hq[0] + hq[1];
         sum = sum + hq[2];
-        if (r + 1 < NIT) {
+        if (!(C2M_CORRF_ABL & 2) && r + 1 < NIT) {
           hq[0] = a0[(r + 1) * TQ * WT];
           hq[1] = a1[(r + 1) * TQ * WT];
           hq[2] = a2[(r + 1) * TQ * WT];
@@ -385,7 +397,10 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
       return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
     };
     float hh[TPQ];
-    {
+    if (C2M_CORRF_ABL & 8) {
+#pragma unroll
+      for (int r = 0; r < TPQ; ++r) hh[r] = acc[r];
+    } else {
       float dv[16], tt[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dv[r] = acc[r];
@@ -400,7 +415,7 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     {
       float* dst = ring + sl0 * SLAB + store_off;
 #pragma unroll
-      for (int r = 0; r < TPQ; ++r) dst[r * WT] = hh[r];
+      for (int r = 0; r < ((C2M_CORRF_ABL & 8) ? 1 : TPQ); ++r) dst[r * WT] = hh[r];
     }
 
     if (xtn != xt) sk = skb[min(xtn, nxt - 1)];

@@ -30,6 +30,7 @@ for stage in "$@"; do
     ab_bf)      (for lib in "" $R/build_exp/${AB_LIB:-libc2m_base.so} "" $R/build_exp/${AB_LIB:-libc2m_base.so}; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_branch_free.log 2>&1
                 (echo "=== in-tree (branch-free chunk loop)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600
                  echo "=== C2M_LIB=build_exp/${AB_LIB:-libc2m_base.so}"; C2M_LIB=$R/build_exp/${AB_LIB:-libc2m_base.so} timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600) > $O/ab_branch_free_step.log 2>&1 ;;
+    abl_corrf)  (for lib in "" ${CF_LIBS:-cf1 cf2 cf4 cf8 cf16 cf3 cf15} ""; do echo "=== ${lib:-in-tree} (C2M_CORRF_ABL: 1 B operands reused, 2 no ring reads, 4 no tap rounds, 8 no row-sum tail, 16 no MFMAs)"; C2M_LIB=${lib:+$R/build_exp/libc2m_$lib.so} timeout 120 python scripts/abl_corr_filter.py 2>&1 | grep "^{"; done) > $O/abl_corr_filter.log 2>&1 ;;
     test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
     bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
