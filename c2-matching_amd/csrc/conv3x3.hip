@@ -1252,11 +1252,19 @@ struct Params {
   float* out2;          // optional 8-channel group-major twin (see conv::Params::out2)
   int out2_row_pitch;
   long long out2_plane_pitch, out2_img_pitch;
+  unsigned out_bytes, out2_bytes;   // bytes one image's stores may touch, from its own base (buffer-descriptor records; < 2^31)
 };
 }  // namespace c3
 
+// C2M_C3_ABL (compile-time, measurement builds only; scripts/abl_c3.py): 1 one store of eight, 2 no MFMAs, 4 the image tile is
+// fetched and staged once per workgroup
+#ifndef C2M_C3_ABL
+#define C2M_C3_ABL 0
+#endif
+template <int ACT, bool OUT2>
 __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
   using namespace c3;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   __shared__ float tile[2][NEL];
   const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1299,22 +1307,35 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
     for (int c = 0; c < 3; ++c) { mean_[c] = p.mean[c]; std3[c] = p.std_[c]; }
   }
   const int ntile = p.tiles_x * p.tiles_y * p.B;
+  // The next tile's pixels are fetched RAW with buffer loads (one descriptor per image; a halo element outside the image gets an
+  // offset beyond the records and reads 0.0) right after the barrier and normalised only when they are written to LDS, one
+  // tile later: no branch, no wait between the eight loads, and -- the stores below being unconditional buffer stores as well --
+  // a counted wait (`vmcnt(stores issued since)`) in front of the staging writes instead of a drain of the tile's 32 stores.
   float stage[EPT];
+  unsigned okm = 0u;   // bit i: element i of the staged tile lies inside the image
+  const unsigned in_bytes = (unsigned)(3 * p.H * p.W) * 4u;
   auto fetch = [&](int t) __attribute__((always_inline)) {
     const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
-    const float* ib = p.in + (size_t)b * 3 * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t irs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)b * 3 * p.H * p.W), 0, (int)in_bytes, 0x00020000);
+    okm = 0u;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int y = ty * CTH - 1 + s_ry[i], x = tx * CTW - 1 + s_rx[i];
-      const bool ok = s_c[i] >= 0 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      float v = 0.0f;
-      if (ok) {
-        v = ib[((size_t)s_c[i] * p.H + y) * p.W + x];
-        if (p.mean) v = (v - (s_c[i] == 0 ? mean_[0] : s_c[i] == 1 ? mean_[1] : mean_[2])) /
-                        (s_c[i] == 0 ? std3[0] : s_c[i] == 1 ? std3[1] : std3[2]);
-      }
-      stage[i] = v;
+      const unsigned bad = (s_c[i] < 0) | (y < 0) | (y >= p.H) | (x < 0) | (x >= p.W);
+      const unsigned off = (unsigned)((s_c[i] * p.H + y) * p.W + x) * 4u;
+      stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, off | (bad << 31), 0, 0));
+      okm |= (bad ^ 1u) << i;
     }
+  };
+  auto staged = [&](int i) __attribute__((always_inline)) {   // (x - mean) / std; the padding is zero in the normalised domain
+    // (without mean / std: (x - 0) / 1, exact).  Element tid + 256 i lies in channel (256 i) / PLANE or the next one: the
+    // constants are compile-time per round, or one select -- not a three-way choice hipcc turns into divergent branches
+    const int c_lo = (256 * i) / PLANE, c_hi = (256 * i + 255) / PLANE > 2 ? 2 : (256 * i + 255) / PLANE;
+    const bool up = c_hi != c_lo && tid + 256 * i >= c_hi * PLANE;
+    const float m = up ? mean_[c_hi] : mean_[c_lo], sd = up ? std3[c_hi] : std3[c_lo];
+    const float v = (stage[i] - m) / sd;
+    return ((okm >> i) & 1u) ? v : 0.0f;
   };
   float bias4[2][4][4];
 #pragma unroll
@@ -1324,17 +1345,38 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) bias4[mt][qd][e] = p.bias ? p.bias[mt * 32 + 8 * qd + 4 * hi + e] : 0.0f;
 
-  int t = blockIdx.x;
-  if (t < ntile) fetch(t);
-  for (int it = 0; t < ntile; t += gridDim.x, ++it) {
-    float* buf = tile[it & 1];
+  // every prologue load is waited for HERE: a register still pending at the loop entry would make hipcc wait for ALL memory
+  // traffic (vmcnt(0): the tile fetch just issued included) at its first use in every iteration
+#pragma unroll
+  for (int k = 0; k < 14; ++k) asm volatile("" ::"v"(wreg[k][0]), "v"(wreg[k][1]));
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) asm volatile("" ::"v"(bias4[mt][qd][0]), "v"(bias4[mt][qd][1]), "v"(bias4[mt][qd][2]), "v"(bias4[mt][qd][3]));
+  asm volatile("" ::"v"(mean_[0]), "v"(mean_[1]), "v"(mean_[2]), "v"(std3[0]), "v"(std3[1]), "v"(std3[2]));
+  // Loop shape: the FIRST tile is fetched and staged here; iteration `it` = barrier, fetch of tile it + 1 (raw), the four groups
+  // of tile `it` with their 32 (64) stores, then -- in the same straight-line body, so that hipcc can count the stores issued
+  // since the fetch instead of draining them -- the normalised staging writes of tile it + 1 into the other buffer, which was
+  // last read in iteration it - 1, i.e. before this iteration's barrier.  Past the last tile the fetch repeats the last tile
+  // (unconditional: no branch for the wait count to be merged over) into a buffer nobody reads.
+  auto stage_to = [&](float* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < EPT; ++i)
-      if (s_c[i] >= 0) buf[s_off[i]] = stage[i];
-    __syncthreads();   // tile `it` staged; the buffer written next iteration was last read two barriers ago
-    if (t + (int)gridDim.x < ntile) fetch(t + gridDim.x);
+      if (256 * (i + 1) <= NEL || s_c[i] >= 0) buf[s_off[i]] = staged(i);   // (only the last round is partial)
+  };
+  int t = blockIdx.x;
+  if (t < ntile) {
+    fetch(t);
+    stage_to(tile[0]);
+  }
+  for (int it = 0; t < ntile; t += gridDim.x, ++it) {
+    __syncthreads();   // tile `it` staged; everybody has left tile it - 1
+    if (!(C2M_C3_ABL & 4)) fetch(min(t + (int)gridDim.x, ntile - 1));
     const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
-    const unsigned tb = lds0 + (it & 1) * (NEL * 4);
+    const unsigned tb = lds0 + ((C2M_C3_ABL & 4) ? 0 : it & 1) * (NEL * 4);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.out_img_pitch, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors2 = __builtin_amdgcn_make_buffer_rsrc(
+        OUT2 ? p.out2 + (size_t)b * p.out2_img_pitch : p.out, 0, OUT2 ? (int)p.out2_bytes : 0, 0x00020000);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {   // the wave's groups: rows 2 wv + (g >> 1), columns 32 (g & 1) + j
       const int row = 2 * wv + (g >> 1), col = 32 * (g & 1);
@@ -1355,10 +1397,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
 #pragma unroll
       for (int k = 0; k < 14; ++k)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][mt], bv[k], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+          if (C2M_C3_ABL & 2) acc[mt][k] += wreg[k][mt] * bv[k];
+          else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][mt], bv[k], acc[mt], 0, 0, 0);
+        }
       const int y = ty * CTH + row, x = tx * CTW + col + j;
-      if (y < p.H && x < p.W) {
-        float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + 4 * hi;
+      {
+        const unsigned bad = (unsigned)(y >= p.H) | (unsigned)(x >= p.W);
+        const unsigned ob = ((unsigned)(y * p.out_row_pitch + x * p.out_pix_pitch + 4 * hi) * 4u) | (bad << 31);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1367,17 +1413,23 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[e] = acc[mt][4 * qd + e] + bias4[mt][qd][e];
-              if (p.act == 1) v[e] = fmaxf(v[e], 0.0f);
-              else if (p.act == 2) v[e] = fmaxf(v[e], v[e] * p.slope);
+              if (ACT == 1) v[e] = fmaxf(v[e], 0.0f);
+              else if (ACT == 2) v[e] = fmaxf(v[e], v[e] * p.slope);
             }
             const int co = mt * 32 + 8 * qd + 4 * hi;
-            *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
-            if (p.out2)
-              *reinterpret_cast<f32x4*>(p.out2 + (size_t)b * p.out2_img_pitch + (size_t)(co >> 3) * p.out2_plane_pitch +
-                                        (size_t)y * p.out2_row_pitch + x * 8 + (co & 7)) = v;
+            if ((C2M_C3_ABL & 1) && (mt + qd != 0) && v[0] != 12345.678f) continue;
+            // (the channel offset goes into the instruction's IMMEDIATE offset, the plane offset into the vector offset: a 128-bit
+            // buffer store with an SGPR soffset whose data registers a VALU overwrites within two issue slots stores garbage in
+            // lanes 12..15 / 28..31 of each half on gfx950 -- hipcc pads only the immediate-soffset form of that hazard)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ors, ob + (unsigned)((mt * 32 + 8 * qd) * 4), 0, 0);
+            if (OUT2)
+              __builtin_amdgcn_raw_buffer_store_b128(
+                  __builtin_bit_cast(u32x4_t, v), ors2,
+                  (((unsigned)(y * p.out2_row_pitch + x * 8 + (co & 7)) + (unsigned)(co >> 3) * (unsigned)p.out2_plane_pitch) * 4u) | (bad << 31), 0, 0);
           }
       }
     }
+    if (!(C2M_C3_ABL & 4)) stage_to(tile[(it + 1) & 1]);
   }
 }
 
@@ -1487,10 +1539,18 @@ extern "C" int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, in
   p.out2_img_pitch = out2_img_pitch;
   const long long ntile = (long long)p.tiles_x * p.tiles_y * B;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
+  // buffer addressing inside one image: every byte offset, and bit 31 as the "outside" mark, must fit 32 bits
+  const long long in_b = 12LL * H * W, out_b = 4LL * ((long long)(H - 1) * out_row_pitch + (long long)(W - 1) * out_pix_pitch + 64),
+                  out2_b = out2 ? 4LL * (7 * out2_plane_pitch + (long long)(H - 1) * out2_row_pitch + 8LL * W) : 0;
+  if (in_b >= (1LL << 31) || out_b >= (1LL << 31) || out2_b >= (1LL << 31) || out_row_pitch < 0 || out_pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
+  p.out_bytes = (unsigned)out_b; p.out2_bytes = (unsigned)out2_b;
   hipStream_t st = as_stream(stream);
   ProfileScope prof(C2M_KERNEL_CONV3X3, st);
   // persistent workgroups (the weights stay in registers): 3 fit a CU (164 VGPRs), tiles strided over them
-  hipLaunchKernelGGL(conv::conv3x3_c3_kernel, dim3((unsigned)std::min<long long>(ntile, 768)), dim3(256), 0, st, p);
+  void (*kern)(conv::c3::Params) =
+      out2 ? (act == 0 ? &conv::conv3x3_c3_kernel<0, true> : act == 1 ? &conv::conv3x3_c3_kernel<1, true> : &conv::conv3x3_c3_kernel<2, true>)
+           : (act == 0 ? &conv::conv3x3_c3_kernel<0, false> : act == 1 ? &conv::conv3x3_c3_kernel<1, false> : &conv::conv3x3_c3_kernel<2, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(ntile, 768)), dim3(256), 0, st, p);
   return check_launch();
 }
 

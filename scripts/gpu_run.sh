@@ -31,6 +31,7 @@ for stage in "$@"; do
                 (echo "=== in-tree (branch-free chunk loop)"; timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600
                  echo "=== C2M_LIB=build_exp/${AB_LIB:-libc2m_base.so}"; C2M_LIB=$R/build_exp/${AB_LIB:-libc2m_base.so} timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-1600) > $O/ab_branch_free_step.log 2>&1 ;;
     abl_corrf)  (for lib in "" ${CF_LIBS:-cf1 cf2 cf4 cf8 cf16 cf3 cf15} ""; do echo "=== ${lib:-in-tree} (C2M_CORRF_ABL: 1 B operands reused, 2 no ring reads, 4 no tap rounds, 8 no row-sum tail, 16 no MFMAs)"; C2M_LIB=${lib:+$R/build_exp/libc2m_$lib.so} timeout 120 python scripts/abl_corr_filter.py 2>&1 | grep "^{"; done) > $O/abl_corr_filter.log 2>&1 ;;
+    abl_c3)     (for lib in "" ${C3_LIBS:-c3a1 c3a2 c3a4 c3a3 c3a7} ""; do echo "=== ${lib:-in-tree} (C2M_C3_ABL: 1 one store of eight, 2 no MFMAs, 4 tile staged once)"; C2M_LIB=${lib:+$R/build_exp/libc2m_$lib.so} timeout 120 python scripts/abl_c3.py 2>&1 | grep "^{"; done) > $O/abl_c3.log 2>&1 ;;
     test_w16)   timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16" 2>&1 | tail -120 > $O/pytest_wino16.log ;;
     bench_w16)  (for a in split16 wino16 wino16_f23; do echo "== $a"; timeout 200 python scripts/bench_conv.py --algo $a --only "body" --iters 20; done) 2>&1 | grep -v "^\[{" > $O/bench_wino16.log ;;
     test_corr)  timeout 900 python -m pytest tests/test_corr_gpu.py -m gpu -q -rA 2>&1 | tail -80 > $O/pytest_corr.log ;;
