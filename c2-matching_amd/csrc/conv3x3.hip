@@ -1252,7 +1252,7 @@ struct Params {
   float* out2;          // optional 8-channel group-major twin (see conv::Params::out2)
   int out2_row_pitch;
   long long out2_plane_pitch, out2_img_pitch;
-  unsigned out_bytes, out2_bytes;   // bytes one image's stores may touch, from its own base (buffer-descriptor records; < 2^31)
+  unsigned out_bytes, out2_bytes;   // bytes one TILE ROW's stores may touch, from its own base (buffer-descriptor records; < 2^31)
 };
 }  // namespace c3
 
@@ -1374,9 +1374,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
     if (!(C2M_C3_ABL & 4)) fetch(min(t + (int)gridDim.x, ntile - 1));
     const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, b = t / (p.tiles_x * p.tiles_y);
     const unsigned tb = lds0 + ((C2M_C3_ABL & 4) ? 0 : it & 1) * (NEL * 4);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.out_img_pitch, 0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors2 = __builtin_amdgcn_make_buffer_rsrc(
-        OUT2 ? p.out2 + (size_t)b * p.out2_img_pitch : p.out, 0, OUT2 ? (int)p.out2_bytes : 0, 0x00020000);
+    // store descriptors start at this tile's first pixel row (and, for the twin, at each 8-channel plane): the 32-bit offsets
+    // then span eight rows whatever the image size
+    float* const obase = p.out + (size_t)b * p.out_img_pitch + (size_t)(ty * CTH) * p.out_row_pitch;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)p.out_bytes, 0x00020000);
+    float* const obase2 = OUT2 ? p.out2 + (size_t)b * p.out2_img_pitch + (size_t)(ty * CTH) * p.out2_row_pitch : obase;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {   // the wave's groups: rows 2 wv + (g >> 1), columns 32 (g & 1) + j
       const int row = 2 * wv + (g >> 1), col = 32 * (g & 1);
@@ -1404,7 +1406,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
       const int y = ty * CTH + row, x = tx * CTW + col + j;
       {
         const unsigned bad = (unsigned)(y >= p.H) | (unsigned)(x >= p.W);
-        const unsigned ob = ((unsigned)(y * p.out_row_pitch + x * p.out_pix_pitch + 4 * hi) * 4u) | (bad << 31);
+        const unsigned ob = ((unsigned)(row * p.out_row_pitch + x * p.out_pix_pitch + 4 * hi) * 4u) | (bad << 31);
+        const unsigned ob2 = ((unsigned)(row * p.out2_row_pitch + x * 8 + 4 * hi) * 4u) | (bad << 31);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1416,16 +1419,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c3_kernel(c3::Params p) {
               if (ACT == 1) v[e] = fmaxf(v[e], 0.0f);
               else if (ACT == 2) v[e] = fmaxf(v[e], v[e] * p.slope);
             }
-            const int co = mt * 32 + 8 * qd + 4 * hi;
             if ((C2M_C3_ABL & 1) && (mt + qd != 0) && v[0] != 12345.678f) continue;
             // (the channel offset goes into the instruction's IMMEDIATE offset, the plane offset into the vector offset: a 128-bit
             // buffer store with an SGPR soffset whose data registers a VALU overwrites within two issue slots stores garbage in
             // lanes 12..15 / 28..31 of each half on gfx950 -- hipcc pads only the immediate-soffset form of that hazard)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ors, ob + (unsigned)((mt * 32 + 8 * qd) * 4), 0, 0);
-            if (OUT2)
-              __builtin_amdgcn_raw_buffer_store_b128(
-                  __builtin_bit_cast(u32x4_t, v), ors2,
-                  (((unsigned)(y * p.out2_row_pitch + x * 8 + (co & 7)) + (unsigned)(co >> 3) * (unsigned)p.out2_plane_pitch) * 4u) | (bad << 31), 0, 0);
+            if (OUT2) {   // plane co >> 3 = 4 mt + qd is the same for the whole wave: it goes into the descriptor's base
+              const __amdgpu_buffer_rsrc_t ors2 = __builtin_amdgcn_make_buffer_rsrc(
+                  obase2 + (size_t)(mt * 4 + qd) * p.out2_plane_pitch, 0, (int)p.out2_bytes, 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ors2, ob2, 0, 0);
+            }
           }
       }
     }
@@ -1539,9 +1542,11 @@ extern "C" int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, in
   p.out2_img_pitch = out2_img_pitch;
   const long long ntile = (long long)p.tiles_x * p.tiles_y * B;
   if (ntile > 0x7fffffffLL) return C2M_ERR_INVALID_ARG;
-  // buffer addressing inside one image: every byte offset, and bit 31 as the "outside" mark, must fit 32 bits
-  const long long in_b = 12LL * H * W, out_b = 4LL * ((long long)(H - 1) * out_row_pitch + (long long)(W - 1) * out_pix_pitch + 64),
-                  out2_b = out2 ? 4LL * (7 * out2_plane_pitch + (long long)(H - 1) * out2_row_pitch + 8LL * W) : 0;
+  // buffer addressing inside one image (loads) / one row of tiles (stores): every byte offset, and bit 31 as the "outside" mark,
+  // must fit 32 bits
+  const long long in_b = 12LL * H * W,
+                  out_b = 4LL * ((long long)(conv::c3::CTH - 1) * out_row_pitch + (long long)(W - 1) * out_pix_pitch + 64),
+                  out2_b = out2 ? 4LL * ((long long)(conv::c3::CTH - 1) * out2_row_pitch + 8LL * W) : 0;
   if (in_b >= (1LL << 31) || out_b >= (1LL << 31) || out2_b >= (1LL << 31) || out_row_pitch < 0 || out_pix_pitch < 0) return C2M_ERR_UNSUPPORTED;
   p.out_bytes = (unsigned)out_b; p.out2_bytes = (unsigned)out2_b;
   hipStream_t st = as_stream(stream);

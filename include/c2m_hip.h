@@ -374,7 +374,8 @@ int c2m_conv3x3_wgrad_f32(c2m_stream_t stream, const c2m_conv_src* src, int nsrc
  * ref_restoration_arch.py:30): image [B][3][H][W] planar fp32, weight [64][3][3][3], bias [64] or NULL;
  * mean / std [3] (both or neither): (image - mean[c]) / std[c] is applied first (vgg_arch.py:137-138), zero padding in the
  * normalised domain.  Output channels-last with the given pitches (floats) + optional activation; out2: optional
- * 8-channel group-major twin (see c2m_conv3x3_desc.out2).
+ * 8-channel group-major twin (see c2m_conv3x3_desc.out2).  One image (12 H W bytes) and eight output rows are addressed with
+ * 32-bit byte offsets; C2M_ERR_UNSUPPORTED beyond 2^31 (an image of 13 000 x 13 000 pixels, rows of 10^6 pixels).
  */
 int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, int B, int H, int W, const float* weight,
                           const float* bias, const float* mean, const float* std_, int act, float slope, float* out,

@@ -5,7 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "c2-matching_amd"))
 import torch
 from c2m_amd import ops
-for (B, H, W, norm) in [(3, 8, 64, True), (1, 8, 64, False), (2, 40, 40, True), (1, 37, 75, False), (1, 131, 200, True), (2, 5, 3, True), (16, 640, 640, True), (4, 1280, 1280, True)]:
+for (B, H, W, norm) in [(3, 8, 64, True), (1, 8, 64, False), (2, 40, 40, True), (1, 37, 75, False), (1, 131, 200, True), (2, 5, 3, True), (16, 640, 640, True), (4, 1280, 1280, True), (1, 3000, 3000, True)]:   # last: one image's output > 2^31 bytes
     g = torch.Generator(device="cuda").manual_seed(5)
     img = torch.rand((B, 3, H, W), generator=g, device="cuda")
     w = torch.randn((64, 3, 3, 3), generator=g, device="cuda") * 0.2
