@@ -263,6 +263,32 @@ def test_conv3x3_rgb64_first_layer(ops, dev, B, H, W, act, norm):
     assert float(bo.buf[:, 0].abs().max()) == 0 and float(bo.buf[:, :, W + 1:].abs().max()) == 0
 
 
+def test_conv3x3_rgb64_first_layer_at_full_size(ops, dev):
+    """The first-layer kernel on a chip-filling launch (configs[2]'s own shape: B=16 at 640 x 640, 12 800 tiles on 768
+    persistent workgroups, three per CU), every image against a stock convolution, repeated, plus the bordered destination
+    with its group-major twin: the store-data hazard this kernel's round-5 rewrite ran into (128-bit buffer stores with a
+    register soffset: lanes 12..15 / 28..31 wrong by O(1)) and anything of its class shows here, not on the
+    small maps above."""
+    B, H, W = 16, 640, 640
+    img = torch.rand((B, 3, H, W), generator=torch.Generator(device=dev).manual_seed(15), device=dev)
+    w = _rand((64, 3, 3, 3), dev, 16, 1.0 / np.sqrt(27))
+    b = _rand((64,), dev, 17)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    want = torch.cat([F.conv2d((img[i:i + 1] - mean) / std, w, b, padding=1).relu() for i in range(B)])
+    tol = 1e-5 * max(1.0, float(want.abs().max()))
+    first = None
+    for rep in range(3):
+        got = ops.conv3x3_rgb64(img, w, b, act=ops.ACT_RELU, mean=mean, std=std)
+        assert float((got - want).abs().max()) < tol, rep
+        first = got if first is None else first
+        assert torch.equal(got, first), rep
+    bo = ops._bordered_empty(B, 64, H, W, dev, grouped8=True)
+    ops.conv3x3_rgb64(img, w, b, act=ops.ACT_RELU, mean=mean, std=std, out=bo.interior(), out2_grouped8=bo.grouped8)
+    assert torch.equal(bo.interior(), first)
+    assert torch.equal(bo.grouped8, bo.buf.view(B, H + 3, W + 3, 8, 8).permute(0, 3, 1, 2, 4).contiguous())
+
+
 WINO_CASES = [
     # B, [Cin per source], Cout, H, W, act, n residuals     (W % 32 == 0, Cout % 64 == 0, channels % 16 == 0)
     (2, [64], 64, 12, 64, 1, 0),
