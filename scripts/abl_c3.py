@@ -10,6 +10,7 @@ from c2m_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+TWIN = len(sys.argv) > 3 and sys.argv[3] == "twin"   # bordered destination + 8-channel group-major twin (what the VGG tap writes)
 g = torch.Generator(device="cuda").manual_seed(1)
 img = torch.rand((B, 3, N, N), generator=g, device="cuda")
 w = torch.randn((64, 3, 3, 3), generator=g, device="cuda") * 0.2
@@ -19,13 +20,19 @@ std = torch.tensor([0.229, 0.224, 0.225], device="cuda").view(1, 3, 1, 1)
 out = ops.conv3x3_rgb64(img, w, b, act=1, mean=mean, std=std)
 want = torch.nn.functional.conv2d(((img - mean) / std)[:1], w, b, padding=1).relu()
 err = float((out[:1] - want).abs().max())
+kw = {"out": out}
+if TWIN:
+    bo = ops._bordered_empty(B, 64, N, N, "cuda", grouped8=True)
+    kw = {"out": bo.interior(), "out2_grouped8": bo.grouped8}
+    ops.conv3x3_rgb64(img, w, b, act=1, mean=mean, std=std, **kw)
+    err = max(err, float((bo.interior()[:1] - want).abs().max()))
 c2m_amd.profile_enable(True); c2m_amd.profile_collect()
 for _ in range(10):
-    ops.conv3x3_rgb64(img, w, b, act=1, mean=mean, std=std, out=out)
+    ops.conv3x3_rgb64(img, w, b, act=1, mean=mean, std=std, **kw)
 torch.cuda.synchronize()
 ms = [m for (nm, m) in c2m_amd.profile_collect()]
 c2m_amd.profile_enable(False)
 ms.sort()
 gb = B * 64 * N * N * 4 / 1e9
 print({"ms_median": round(ms[len(ms) // 2], 4), "ms_min": round(ms[0], 4), "write_GBs": round(gb / ms[len(ms) // 2] * 1e3, 1),
-       "max_err_vs_torch": err, "lib": os.environ.get("C2M_LIB", "in-tree")})
+       "max_err_vs_torch": err, "twin": TWIN, "lib": os.environ.get("C2M_LIB", "in-tree")})
