@@ -2,6 +2,8 @@
 
 The operator is floating point; fp32 MFMA is an exact fmaf chain, so the only freedom against a reference convolution is
 the summation order: tolerance 1e-5 * scale against F.conv2d evaluated in float64 (what VERDICT r1 item 7 asks for)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -908,3 +910,14 @@ def test_f16_range_guard_switches_a_module_to_bf16x3(ops, dev):
         assert all(torch.equal(again[k], got[k]) for k in got)
         small = vgg(torch.rand(1, 3, 40, 48, device=dev))         # stays on bf16 x 3 (finite either way)
         assert all(bool(torch.isfinite(v).all()) for v in small.values())
+
+
+def test_loader_matrix_wave_kernel_opt_in(dev):
+    """csrc/conv3x3_pc.hip ($C2M_CONV_PC=1: the f16 x 2 arithmetic with loader and matrix waves, DESIGN.md 6.10 -- measured
+    slower than the split kernel, kept opt-in): ragged, multi-chunk and chip-filling 64-cout layers against float64 and the
+    fp32-MFMA kernel, bit-identical repeats.  A process of its own: the switch is read once per process."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, C2M_CONV_PC="1", C2M_CONV_PC_MINPIX="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "diag_pc.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
