@@ -42,10 +42,16 @@ for _p in (os.path.join(REPO, "c2-matching_amd"),):
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
-BF16_SUSTAINED_TFLOPS = 1780.0    # scripts/ubench/mfma_bf16_rate: back-to-back MFMAs on all 1024 SIMDs with non-zero operands
-                                  # (the chip clocks down to ~1.7 GHz under that load: profiles/r03_ubench_mfma_bf16_rate.log)
+# what the 16-bit matrix pipe SUSTAINS (back-to-back MFMAs on all 1024 SIMDs, nothing else): it depends on the operand values
+# (power).  Random-valued operand sets that change from one MFMA to the next -- what a convolution feeds it: 1440 - 1630
+# (scripts/ubench/mfma_power_share.hip, profiles/r05_ubench_mfma_power_share.log) -> 1530 prices the matrix
+# floor.  Constant non-zero operands: 1780 (profiles/r03_ubench_mfma_bf16_rate.log), kept as a second key.
+BF16_SUSTAINED_TFLOPS = 1530.0
+BF16_SUSTAINED_CONST_OPERANDS_TFLOPS = 1780.0
 HBM_PEAK_GBS = 8000.0
 HBM_ACHIEVABLE_GBS = 6300.0       # same guide: what a streaming kernel gets
+PARITY_SR_TOL = 1e-3              # BASELINE.json north_star: "SR pixels within 1e-3 abs fp32"
+PARITY_FLIP_MARGIN = 1e-6         # an index-map flip against the CPU chain must be an fp32 near-tie (float64 margin below this)
 METRIC = "LR-Ref image pairs/sec (160x160 LR, 500x500 Ref, 4x SR)"
 
 
@@ -146,6 +152,7 @@ def corr_roofline(B, C, h, kms, n, pmc, swept=None):
             "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": _rnd(_tf(exec_flops, kms) / FP32_MATRIX_PEAK_TFLOPS),
             "traffic": pmc.get("corr_hbm_bytes_per_launch"), "kernel_ms": _rnd(kms, 3), "launches_timed": n,
             "executed_flops_per_launch": exec_flops, "algorithmic_flops_per_launch": algo,
+            "algorithmic_frac": _rnd(_tf(algo, kms) / FP32_MATRIX_PEAK_TFLOPS),
             "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None}
 
 
@@ -163,6 +170,10 @@ def corr_filter_roofline(B, C, h, kern, pmc, swept=None):
             "frac": _rnd(_tf(execd, fms) / BF16_MATRIX_PEAK_TFLOPS), "traffic": pmc.get("corr_filter_hbm_bytes_per_launch"),
             "kernel_ms": _rnd(fms, 3), "launches_timed": len(fk), "resolve_ms": _rnd(sum(rk) / max(len(rk), 1), 3),
             "executed_flops_per_launch": execd, "algorithmic_flops_per_launch": algo,
+            # SURVEY 8d counts the reference's conv2d formulation (2*Nq*Nr*C*9); the diagonal-sum restructuring issues 8.6x fewer
+            # products and skips duplicate ref rows, so the 8d figure over the f16 peak can exceed 1 -- no work is skipped
+            # (bit-exact full maps), fewer products are needed
+            "algorithmic_frac": _rnd(_tf(algo, fms) / BF16_MATRIX_PEAK_TFLOPS),
             "ref_rows_swept": swept[0] if swept else None, "ref_rows_full_sweep": swept[1] if swept else None}
 
 
@@ -175,7 +186,7 @@ def dcn_roofline(name, B, C, Co, H, kms, n, traffic=None, src=None, f16x2=False)
     peak = BF16_MATRIX_PEAK_TFLOPS if f16x2 else FP32_MATRIX_PEAK_TFLOPS
     return {"k": f"dcn_{name}", "bound": "mfma", "pipe": "f16 MFMA x3" if f16x2 else "fp32 MFMA", "kernel": f"dcn_v2_forward[{name}: C={C}, {H}x{H}]",
             "achieved": _rnd(_tf(execd, kms), 2), "peak": peak, "unit": "TFLOP/s", "frac": _rnd(_tf(execd, kms) / peak),
-            "frac_vs_fp32_pipe": _rnd(_tf(flops, kms) / FP32_MATRIX_PEAK_TFLOPS),
+            "frac_vs_fp32_pipe": _rnd(_tf(flops, kms) / FP32_MATRIX_PEAK_TFLOPS), "algorithmic_frac": _rnd(_tf(flops, kms) / peak),
             "traffic": traffic, "kernel_ms": _rnd(kms, 3), "launches_timed": n, "algorithmic_flops_per_launch": flops,
             "executed_flops_per_launch": execd}
 
@@ -200,9 +211,13 @@ def conv_rooflines(kern, fam, steps, pmc):
              "achieved": _rnd(_tf(execd, kms), 1), "peak": peak, "unit": "TFLOP/s", "frac": _rnd(_tf(execd, kms) / peak),
              "kernel_ms": _rnd(kms, 2), "launches_timed": len(ms), "algorithmic_flops_per_launch": algo,
              "executed_flops_per_launch": execd, "algorithmic_equiv_tflops": _rnd(_tf(algo, kms), 1),
+             # `frac` = EXECUTED matrix flops / dense peak (f16 x 2: three products per algorithmic product);
+             # `algorithmic_frac` = SURVEY 8d's algorithmic flops / the same peak -- the figure 8d's recipe gives
+             "algorithmic_frac": _rnd(_tf(algo, kms) / peak),
              "traffic": pmc.get(f"{kid}_hbm_bytes_per_step")}
         if kid == "conv3x3_split":
             e["frac_of_sustained_rate"] = _rnd(_tf(execd, kms) / BF16_SUSTAINED_TFLOPS)
+            e["sustained_tflops"] = {"changing_random_operands": BF16_SUSTAINED_TFLOPS, "constant_operands": BF16_SUSTAINED_CONST_OPERANDS_TFLOPS}
             # the family has TWO roofs: the matrix pipe at the rate it sustains on non-zero operands and HBM at
             # the ~6.3 TB/s it delivers; `sum` = what a kernel whose memory and matrix phases do not overlap at all would take
             if e["traffic"]:
@@ -379,6 +394,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra passes on the other convolution arithmetics")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="bf16: inference under torch.autocast(bfloat16) (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experimental", action="store_true",
+                    help="also time the step on the Winograd-along-y kernels of csrc/experimental/ (a library built with `make "
+                         "EXPERIMENTAL=1`; round 5's recorded no-go, DESIGN.md 6.7)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch-path check without a GPU workload: respawn under torch.distributed.run, read RANK / LOCAL_RANK / "
                          "WORLD_SIZE, init the process group ($C2M_BENCH_BACKEND, default nccl = RCCL; gloo on a CPU-only host), "
@@ -461,10 +479,15 @@ def main():
         ops.count_conv_flops(False)
         prof = c2m_amd.profile_collect(capacity=65536)
         c2m_amd.profile_enable(False)
+        timed.rank_step_ms = None
         if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            # the line's time is the MAX over ranks (driver contract); the MIN travels with it so that a scaling loss can be
+            # attributed: min ~ max -> every rank slowed down (shared resource), min << max -> one straggler
+            t = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            timed.rank_step_ms = {"min_over_ranks": _rnd(-float(t[1].item()) / args.steps * 1e3, 3),
+                                  "max_over_ranks": _rnd(float(t[0].item()) / args.steps * 1e3, 3), "this_rank": _rnd(dt / args.steps * 1e3, 3)}
+            dt = float(t[0].item())
         kern = {}
         for name, ms in prof:
             kern.setdefault(name, []).append(ms)
@@ -487,6 +510,7 @@ def main():
                          f"`python bench.py`, {pmc.get('measured_at', 'see profiles/README.md')}; not re-measured in this run)")
     base = {"unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic", "rccl_world_size": rccl_world}
+    timed.rank_step_ms = None
 
     # ---- configs[3]: stage-3 training step ---------------------------------------------------------------------------
     if train:
@@ -541,7 +565,8 @@ def main():
                     gradient_allreduce_bytes_per_step_per_gpu=grad_bytes if dist is not None else 0,
                     net_g_gradient_bytes=grad_bytes, loss=float(loss), hip_graph=bool(opt["train"]["hip_graph"]),
                     train_kernels=os.environ.get("C2M_TRAIN_KERNELS", "auto"), pairs_of_this_rank=mine[:4] + ["..."],
-                    c2m_kernel_ms_per_step={k: _rnd(sum(v) / args.steps, 3) for k, v in kern.items()})
+                    c2m_kernel_ms_per_step={k: _rnd(sum(v) / args.steps, 3) for k, v in kern.items()},
+                    rank_step_ms=timed.rank_step_ms)
         return finish(line)
 
     # ---- configs[1] leg: correlation only on synthetic features (sub-record of the default line) --------------------
@@ -568,6 +593,7 @@ def main():
                     roofline=corr_filter_roofline(B, C, h, kern, pmc, swept) if filt else
                     corr_roofline(B, C, h, sum(ck) / max(len(ck), 1), len(ck), pmc, swept))
         line["c2m_kernel_ms_per_step"] = {k: round(sum(v) / args.steps, 4) for k, v in kern.items()}
+        line["rank_step_ms"] = timed.rank_step_ms
         if world == 1 and not args.no_cpu_baseline and rank == 0:
             line["cpu_baseline"] = cpu_baseline_corr(h, C)
         return finish(line)
@@ -596,6 +622,7 @@ def main():
         return sr
 
     dt, kern, sr = timed(restore_step)
+    rank_ms = timed.rank_step_ms
     pre_timed = last["pre"]     # (the extra passes on other arithmetics below overwrite last["pre"])
     fam = timed.families
     swept = corr_swept_rows(h)   # of the timed steps' correlation launch (same inputs every step)
@@ -655,7 +682,7 @@ def main():
                     config={"workload": cfg, "parallelism": f"dp{world} (batch-sharded, no collective)"},
                     stage_ms={k: _rnd(v, 2) for k, v in stage.items()}, kernel_table=table, roofline=dominant,
                     c2m_kernel_ms_per_step={k: _rnd(sum(v) / args.steps, 3) for k, v in kern.items()},
-                    configs1_corr_only=sub, notes="profiles/bench_notes.md")
+                    configs1_corr_only=sub, notes="profiles/bench_notes.md", rank_step_ms=rank_ms)
         if not bf16:
             try:   # measured, on this GPU, in this run: distance of every convolution arithmetic from a float64 convolution
                 g_ = torch.Generator(device=dev).manual_seed(77)
@@ -665,7 +692,10 @@ def main():
                 want = torch.nn.functional.conv2d(xe.double(), we.double(), be.double(), padding=1)
                 chk = {}   # [max abs, rms] error on a 256 -> 256 layer (K = 2304, outputs ~5)
                 from c2m_amd import ops as _o
-                for name, algo in (("fp32_mfma", "direct"), ("f16x2", "split16"), ("bf16x3", "split"), ("wino16_f43y", "wino16"), ("wino16_f23y", "wino16_f23")):
+                arith = [("fp32_mfma", "direct"), ("f16x2", "split16"), ("bf16x3", "split")]
+                if args.experimental and _o.experimental_built():
+                    arith += [("wino16_f43y", "wino16"), ("wino16_f23y", "wino16_f23")]
+                for name, algo in arith:
                     d_ = (_o.conv3x3(xe, we, be, algo=algo).double() - want)
                     chk[name] = [float(f"{float(d_.abs().max()):.3g}"), float(f"{float(d_.pow(2).mean().sqrt()):.3g}")]
                 line["conv_error_vs_fp64"] = chk
@@ -697,21 +727,33 @@ def main():
                     _ops._SPLIT16, _ops._SPLIT = keep
                     with _ops.corr_filter_mode(0):
                         line["value_exact_corr_sweep"] = _rnd(rerun(n_alt), 2)
-                    # round 5's go / no-go on Winograd-along-y over the f16 x 2 pieces (csrc/conv3x3_wino16.hip; opt-in): the same
-                    # step with every eligible channels-last layer on the F(4,3) / F(2,3) kernel
-                    keep_w = _ops._WINO16
-                    try:
-                        _ops._WINO16 = 7
-                        line["value_wino16_f43y_convolutions"] = _rnd(rerun(n_alt), 2)
-                        _ops._WINO16 = 8
-                        line["value_wino16_f23y_convolutions"] = _rnd(rerun(n_alt), 2)
-                    finally:
-                        _ops._WINO16 = keep_w
+                    # round 5's go / no-go on Winograd-along-y over the f16 x 2 pieces (csrc/experimental/conv3x3_wino16.hip): the
+                    # same step with every eligible channels-last layer on the F(4,3) / F(2,3) kernel -- only with --experimental
+                    # on a library built with `make EXPERIMENTAL=1` (the no-go is recorded: DESIGN.md 6.7)
+                    if args.experimental and _ops.experimental_built():
+                        keep_w = _ops._WINO16
+                        try:
+                            _ops._WINO16 = 7
+                            line["value_wino16_f43y_convolutions"] = _rnd(rerun(n_alt), 2)
+                            _ops._WINO16 = 8
+                            line["value_wino16_f23y_convolutions"] = _rnd(rerun(n_alt), 2)
+                        finally:
+                            _ops._WINO16 = keep_w
                 finally:
                     _ops._SPLIT16, _ops._SPLIT = keep
         if world == 1 and not args.no_cpu_baseline and not bf16:
             idx_gpu = pre_timed.max_idx.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline_restore(ext, mp, net, lq, up, ref, sr, idx_gpu)
+            # north_star's tolerance as an ASSERTION of the run: given the GPU's own index map the SR image must
+            # agree with the CPU chain to 1e-3 (measured ~1e-7), and an index-map flip is only acceptable as an fp32 near-tie
+            # (float64 margin of the two candidates < 1e-6; measured ~1e-7).  The line is printed either way; the exit code says it.
+            par = line["cpu_baseline"]["parity_gpu_vs_cpu"]
+            bad = [q for q in par if q["sr_max_abs_diff_given_gpu_index_map"] > PARITY_SR_TOL or q["max_fp64_margin_of_flips"] > PARITY_FLIP_MARGIN]
+            line["parity_ok"] = not bad
+            if bad:
+                finish(line)
+                raise SystemExit(f"bench.py: parity violated on pairs {[q['pair'] for q in bad]} (SR given the GPU index map > {PARITY_SR_TOL} "
+                                 f"or an index flip with float64 margin > {PARITY_FLIP_MARGIN}): {bad}")
     finish(line)
 
 

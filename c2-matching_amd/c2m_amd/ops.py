@@ -57,10 +57,11 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
         ws = torch.empty(nbytes, dtype=torch.uint8, device=fi.device)
         idx = torch.empty((B, Hqp, Wqp), dtype=torch.int64, device=fi.device)
         val = torch.empty((B, Hqp, Wqp), dtype=torch.float32, device=fi.device)
-        _lib.check(L.c2m_feature_match_index_f32(_stream(), fi.data_ptr(), fr.data_ptr(), B, C, Hq, Wq, Hr, Wr, p, si,
-                                                 sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
-                                                 idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes),
-                   "c2m_feature_match_index_f32")
+        with _apply_switch("filter"):
+            _lib.check(L.c2m_feature_match_index_f32(_stream(), fi.data_ptr(), fr.data_ptr(), B, C, Hq, Wq, Hr, Wr, p, si,
+                                                     sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
+                                                     idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes),
+                       "c2m_feature_match_index_f32")
         mfma = (not force_generic) and p == 3 and si == 1 and sr == 1 and C in (64, 128, 256)   # the C-ABI's own dispatch rule
         if return_skip or _corr_diag.enabled:
             # diagnostics only (bench.py's swept-row count, the dedup tests): the duplicate-row table exists only when the
@@ -129,35 +130,74 @@ def last_corr_filter_tables():
     return _corr_diag.filter
 
 
-class corr_filter_mode:
-    """`with ops.corr_filter_mode(0): ...` -- exact fp32 sweep only; (1): pre-filter + exact re-score (default); results are
-    identical (c2m_feature_match_set_filter).  Per calling thread (thread_local in the library): measurement / tests."""
+# The library's two A/B switches (c2m_feature_match_set_filter, c2m_conv3x3_set_head_stores) are thread_local: a launch sees the
+# CALLING thread's setting.  The context managers below therefore also record the mode process-wide, and the op wrappers
+# re-apply it on whichever thread launches (under nn.DataParallel the replicas launch from worker threads, where a
+# `with ops.corr_filter_mode(0):` of the main thread used to have no effect -- an A/B pass would have measured the default path
+# without noticing).  Nesting / concurrent use from several threads with DIFFERENT modes is not supported (last writer wins).
+_switch_override = {"filter": None, "head": None}
 
-    def __init__(self, mode):
-        self.mode = int(mode)
+
+class _apply_switch:
+    """Re-apply a recorded process-wide override to this thread's C-ABI switch for the duration of one launch."""
+
+    def __init__(self, which):
+        self.which = which
+        self.mode = _switch_override[which]
+
+    def _set(self, mode):
+        L = _lib.lib()
+        fn = L.c2m_feature_match_set_filter if self.which == "filter" else L.c2m_conv3x3_set_head_stores
+        _lib.check(fn(mode), "c2m set switch")
 
     def __enter__(self):
-        _lib.check(_lib.lib().c2m_feature_match_set_filter(self.mode), "c2m_feature_match_set_filter")
+        if self.mode is not None:
+            self._set(self.mode)
         return self
 
     def __exit__(self, *exc):
-        _lib.check(_lib.lib().c2m_feature_match_set_filter(-1), "c2m_feature_match_set_filter")
+        if self.mode is not None:
+            self._set(-1)
+        return False
+
+
+class corr_filter_mode:
+    """`with ops.corr_filter_mode(0): ...` -- exact fp32 sweep only; (1): pre-filter + exact re-score (default); results are
+    identical (c2m_feature_match_set_filter).  Applies to every thread's launches through this module while the block is open
+    (measurement / tests)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+        if self.mode not in (0, 1):
+            raise _lib.C2MError("corr_filter_mode: 0 or 1")
+
+    def __enter__(self):
+        self.prev = _switch_override["filter"]
+        _switch_override["filter"] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _switch_override["filter"] = self.prev
         return False
 
 
 class head_store_mode:
     """`with ops.head_store_mode(0): ...` -- the DCN head epilogue's dword planar stores; (1): 16-byte stores through the quad
-    transpose + flow window (default where W % 4 == 0); identical results (c2m_conv3x3_set_head_stores).  Per calling thread."""
+    transpose + flow window (default where W % 4 == 0); identical results (c2m_conv3x3_set_head_stores).  Applies to every
+    thread's launches through this module while the block is open."""
 
     def __init__(self, mode):
         self.mode = int(mode)
+        if self.mode not in (0, 1):
+            raise _lib.C2MError("head_store_mode: 0 or 1")
 
     def __enter__(self):
-        _lib.check(_lib.lib().c2m_conv3x3_set_head_stores(self.mode), "c2m_conv3x3_set_head_stores")
+        self.prev = _switch_override["head"]
+        _switch_override["head"] = self.mode
         return self
 
     def __exit__(self, *exc):
-        _lib.check(_lib.lib().c2m_conv3x3_set_head_stores(-1), "c2m_conv3x3_set_head_stores")
+        _switch_override["head"] = self.prev
         return False
 
 
@@ -497,7 +537,24 @@ _SPLIT16 = _os.environ.get("C2M_CONV_SPLIT16", "1") != "0"
 # (round 5): F(4,3) is 6 % faster than the direct f16 x 2 kernel on 64 -> 64 @640^2 and 2-2.5x further from float64
 # than the exact-fp32 kernel on 64-channel layers; F(2,3) is more accurate than the direct kernel and 12 % slower -- the family is
 # bound by vector-memory traffic, not by the matrix pipe.  Not the default; algo="wino16" / "wino16_f23" select it per call.
+# Round 6: the kernel lives in csrc/experimental/ and is only in a library built with `make EXPERIMENTAL=1` (experimental_built()).
 _WINO16 = {"43": 7, "23": 8}.get(_os.environ.get("C2M_CONV_WINO16", "0"), 0)
+
+
+def experimental_built():
+    """True if libc2m_hip.so was built with `make EXPERIMENTAL=1` (csrc/experimental/: the Winograd-along-y and loader /
+    matrix-wave convolution kernels, both measured no-gos kept for their numbers -- DESIGN.md 6.7, 6.10).  Probed once by a
+    one-tile launch: the product library answers algo "wino16" with C2M_ERR_UNSUPPORTED."""
+    v = getattr(experimental_built, "_v", None)
+    if v is None:
+        x = torch.zeros((1, 16, 4, 32), device="cuda").contiguous(memory_format=torch.channels_last)
+        try:
+            conv3x3(x, torch.zeros((64, 16, 3, 3), device="cuda"), algo="wino16_f23")
+            v = True
+        except _lib.C2MError:
+            v = False
+        experimental_built._v = v
+    return v
 # C2M_DCN_F16X2: "1" (default) -- the DCNv2 forward's implicit GEMM follows the convolutions onto the f16 x 2 arithmetic
 _DCN_F16X2 = _os.environ.get("C2M_DCN_F16X2", "1") != "0"
 # internal kernel ids (= weight-cache kinds; 5 is the data-gradient image of the bf16 x 3 kernel) -> c2m_conv3x3_desc.algo
@@ -521,13 +578,8 @@ _range_flags = {}
 _range_lock = _threading.Lock()
 
 
-def _range_flag(dev):
-    """The int32 device flag f16 x 2 launches report into: the enclosing f16_range_guard's OWN flag (one per guard invocation,
-    so that concurrent guards on other threads / streams of the device cannot zero each other's report), else -- explicit
-    algo="split16" / "f16x2" calls outside any guard -- one per device, which the caller may read with range_flag_set()."""
-    g = getattr(_tls, "guard_flag", None)
-    if g is not None and g.device == (dev if dev.index is not None else torch.device(dev.type, torch.cuda.current_device())):
-        return g
+def _device_flag(dev):
+    """The per-device int32 flag (explicit f16 x 2 calls outside any guard report into it; range_flag_set() reads it)."""
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     t = _range_flags.get(key)
     if t is None:
@@ -536,6 +588,16 @@ def _range_flag(dev):
             if t is None:
                 t = _range_flags[key] = torch.zeros(1, dtype=torch.int32, device=dev)
     return t
+
+
+def _range_flag(dev):
+    """The int32 device flag f16 x 2 launches report into: the enclosing f16_range_guard's OWN flag (one per guard invocation,
+    so that concurrent guards on other threads / streams of the device cannot zero each other's report), else -- explicit
+    algo="split16" / "f16x2" calls outside any guard -- one per device, which the caller may read with range_flag_set()."""
+    g = getattr(_tls, "guard_flag", None)
+    if g is not None and g.device == (dev if dev.index is not None else torch.device(dev.type, torch.cuda.current_device())):
+        return g
+    return _device_flag(dev)
 
 
 def _split16_now():
@@ -552,13 +614,29 @@ def _f16x2_auto():
     ov = getattr(_tls, "flavour", None)
     if ov is not None:
         return ov
-    return _SPLIT16 and getattr(_tls, "guarded", False)
+    if getattr(_tls, "guarded", False):
+        return _SPLIT16
+    if _SPLIT16 and not _f16x2_auto.warned and not torch.cuda.is_current_stream_capturing():
+        #  say it once: $C2M_CONV_SPLIT16=1 does NOT make a bare call f16 x 2 -- about twice the matrix work
+        _f16x2_auto.warned = True
+        import warnings
+        warnings.warn("c2m_amd.ops: a conv3x3 / conv3x3_dcn_head / dcn_v2_forward_nhwc call outside `f16_range_guard` and without "
+                      "`ops.conv_flavour(...)` runs the FULL-RANGE arithmetic (bf16 x 3 convolutions, fp32-MFMA DCNv2: ~2x the matrix "
+                      "work of the f16 x 2 default of the fused module forwards).  For f16 x 2 wrap the calls in "
+                      "`with ops.conv_flavour('f16x2'):` and poll `ops.range_flag_set(device)` (domain |x| < 65520); "
+                      "`with ops.conv_flavour('bf16x3'):` silences this.", RuntimeWarning, stacklevel=3)
+    return False
+
+
+_f16x2_auto.warned = False
 
 
 def range_flag_set(device, clear=True):
-    """True if an f16 x 2 launch outside any guard reported an out-of-domain activation on `device` since the last clear (one
-    4-byte read-back)."""
-    f = _range_flag(device)
+    """True if an f16 x 2 launch OUTSIDE any guard reported an out-of-domain activation on `device` (a torch.device, a string
+    or an index) since the last clear (one 4-byte read-back).  Always the per-device flag: called from code that runs under an
+    f16_range_guard it neither sees nor zeroes the guard's own per-invocation flag (ADVICE r5 -- clearing that one would make
+    the guard return f16 x 2 overflow garbage instead of re-running on bf16 x 3)."""
+    f = _device_flag(torch.device("cuda", device) if isinstance(device, int) else torch.device(device))
     v = int(f.item()) != 0
     if clear and v:
         f.zero_()
@@ -897,10 +975,19 @@ def conv3x3_rgb64(image, weight, bias=None, act=ACT_NONE, slope=0.1, mean=None, 
         raise _lib.C2MError("conv3x3_rgb64: weight must be [64,3,3,3]")
     B, _, H, W = x.shape
     dev = x.device
-    w = _dev_f32(weight.detach(), "weight")
-    bias = _dev_f32(bias.detach(), "bias") if bias is not None else None
     if (mean is None) != (std is None):
         raise _lib.C2MError("conv3x3_rgb64: mean and std go together")
+    if 12 * H * W >= 2 ** 31 and out2_grouped8 is None:
+        # the first-layer kernel addresses one image with 32-bit buffer offsets (12 bytes per pixel: H * W < 178 956 971, e.g.
+        # 13 377 x 13 377); beyond that the layer runs on the generic kernel over a 32-channel zero-padded copy (what
+        # ContentExtractor.forward_fused does for first layers that are not 3 -> 64) instead of raising
+        xn = x if mean is None else (x - mean.detach().reshape(1, 3, 1, 1).float()) / std.detach().reshape(1, 3, 1, 1).float()
+        x32 = torch.zeros((B, 32, H, W), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+        x32[:, :3] = xn
+        with conv_flavour("bf16x3"):   # (explicitly full range: no guard needed, no f16 x 2 domain question)
+            return conv3x3(x32, weight, bias, act=act, slope=slope, out=out)
+    w = _dev_f32(weight.detach(), "weight")
+    bias = _dev_f32(bias.detach(), "bias") if bias is not None else None
     if mean is not None:
         mean, std = _dev_f32(mean.detach().reshape(3), "mean"), _dev_f32(std.detach().reshape(3), "std")
     if out is None:
@@ -984,7 +1071,7 @@ def conv3x3_dcn_head(srcs, weight, bias, deformable_groups, flow=None, scale=1, 
             d.abs_sum = abs_sum.data_ptr()
         if wino == 6:
             d.range_flag = _range_flag(dev).data_ptr()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _apply_switch("head"):
             _lib.check(_lib.lib().c2m_conv3x3_nhwc_f32(_stream(), d), "c2m_conv3x3_nhwc_f32")
     if _ConvFlops.enabled:
         for (c0, c1), w_ in zip(slices, fam):

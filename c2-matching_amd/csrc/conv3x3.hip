@@ -1449,7 +1449,11 @@ namespace conv {   // conv3x3_split.hip
 size_t split_relayout_bytes(int Cin, int Cout, int np);
 int split_relayout(hipStream_t st, const float* weight, int Cin, int Cout, int np, void* wr, int dgrad);
 int launch_split(hipStream_t st, Params p, int np);
-int launch_wino16(hipStream_t st, Params p, int R);   // conv3x3_wino16.hip
+#ifdef C2M_EXPERIMENTAL
+int launch_wino16(hipStream_t st, Params p, int R);   // experimental/conv3x3_wino16.hip (make EXPERIMENTAL=1)
+#else
+static inline int launch_wino16(hipStream_t, Params, int) { return C2M_ERR_UNSUPPORTED; }   // measured no-go: not in the product library
+#endif
 int set_head_stores(int mode);
 int split_relayout_multi(hipStream_t st, const long long* jobs, int njobs, long long nblocks, int any_f16);
 }  // namespace conv
@@ -1626,7 +1630,9 @@ extern "C" int c2m_conv3x3_nhwc_f32(c2m_stream_t stream, const c2m_conv3x3_desc*
   for (int sh = 0; sh < 16; ++sh)
     if (d->scale == (1 << sh)) p.scale_shift = sh;
   if (d->out_mode == 3 && d->flow && p.scale_shift < 0) return C2M_ERR_UNSUPPORTED;   // pre-offset scales are powers of two
-  if (d->out_mode == 3 && (long long)cout_total * d->H * d->W * 4 >= 0x7fffffffLL) return C2M_ERR_UNSUPPORTED;   // 32-bit plane offsets
+  // 32-bit byte offsets inside one sample's offset planes [n_off][H][W] and, separately, its mask planes (two buffer resources:
+  // conv3x3_shared.h head_out) -- the same bound the DCNv2 kernel that reads them has (dcn_v2.hip use_nhwc)
+  if (d->out_mode == 3 && (long long)std::max(d->n_off, cout_total - d->n_off) * d->H * d->W * 4 >= 0x7fffffffLL) return C2M_ERR_UNSUPPORTED;
   p.out_vec4 = out_vec4 ? 1 : 0;
   p.co_off = d->out_mode == 3 ? d->cout_offset : 0;
   p.cout_total = cout_total;

@@ -1175,15 +1175,19 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
 }
 
 // p: as filled by c2m_conv3x3_nhwc_f32 (tiles / nchunks / tpw are set here)
-bool pc_supported(const Params& p);          // conv3x3_pc.hip: the same arithmetic with loader / matrix waves
+#ifdef C2M_EXPERIMENTAL
+bool pc_supported(const Params& p);          // experimental/conv3x3_pc.hip: the same arithmetic with loader / matrix waves
 int launch_pc(hipStream_t st, Params p);
+#endif
 
 int launch_split(hipStream_t st, Params p, int np) {
+#ifdef C2M_EXPERIMENTAL
   // $C2M_CONV_PC: 1 = the f16 x 2 flavour's channels-last 64-cout layers on maps of >= C2M_CONV_PC_MINPIX pixels (default 320^2)
-  // run the loader / matrix-wave kernel (same weight images)
+  // run the loader / matrix-wave kernel (same weight images); measured +11 % slower
   static const int env_pc = [] { const char* e = getenv("C2M_CONV_PC"); return e ? atoi(e) : 0; }();
   static const long long pc_minpix = [] { const char* e = getenv("C2M_CONV_PC_MINPIX"); return e ? atoll(e) : 320LL * 320; }();
   if (env_pc != 0 && np == 2 && (long long)p.H * p.W >= pc_minpix && pc_supported(p)) return launch_pc(st, p);
+#endif
   p.tiles_x = ceil_div(p.W, split::TWX);
   p.tiles_y = ceil_div(p.H, split::THY);
   p.nchunks = p.Cin / split::KC;

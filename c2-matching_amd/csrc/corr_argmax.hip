@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(corr::NTHR, 2) corr_argmax_mfma_kernel(
   // from-2 .. to-3 are exact copies of patch row from-3: same scores, same inverse norms, higher index -- they can never
   // win the (larger value, then LOWER index) rule.  The sweep therefore jumps from row from-1 to row `to`; the ring still
   // holds the row sums of rows from-2, from-1, which are the row sums of rows to-2, to-1.  (from == to: nothing skipped.)
+  // A second writer, corr_filter.hip's dead_tiles_kernel, marks whole x-tiles (0, Hr): from = 0 breaks the "from >= 3" contract
+  // above and is only correct because such tiles are a TRAILING set (S below ends the walk before it would enter one; the
+  // invariant and its test are documented at dead_tiles_kernel).
   const int nxt = (Wrp + WP - 1) / WP;
   const int2* __restrict__ skb = skip + (size_t)b * nxt;
   int S = 0;

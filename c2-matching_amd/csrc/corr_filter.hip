@@ -201,6 +201,12 @@ __global__ void __launch_bounds__(256) cand_scale_kernel(const float* __restrict
 // Trailing x-tiles whose every patch is a repeat (first patch column beyond maxcol[b]) are not swept: such a patch ties with a
 // LOWER-indexed one in the filter and in the exact arithmetic alike, it can never be the first maximum (ref_map_util.py:74).
 // Exact and data-dependent like the duplicate-row table it is written into: (0, Hr) = rows [0, Hr) of that (sample, x-tile) skipped.
+// INVARIANT both sweeps rely on (corr_filter_kernel / corr_argmax_mfma_kernel: they subtract every entry from the step count S up
+// front and only test `yn == sk.x` while walking INSIDE a tile, so a (0, Hr) entry is honoured only because the walk never
+// enters such a tile): dead tiles form a TRAILING set -- `xt * WP > maxcol[b]` with maxcol = the LAST patch column holding a
+// non-duplicate patch marks xt and every tile after it, and never tile 0.  A band of all-duplicate columns in the middle of
+// the map is NOT marked (its tiles are swept; tests/test_corr_gpu.py::test_all_duplicate_middle_band_keeps_later_tiles_live).
+// Do not mark non-trailing tiles here without teaching the sweeps to skip into the next live tile.
 __global__ void dead_tiles_kernel(const int* __restrict__ maxcol, int nxt, int n, int Hr, int2* __restrict__ skip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (sample, x-tile)
   if (i >= n) return;
@@ -319,7 +325,7 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
 
     int yn = y + 1, xtn = xt;
     if (yn == sk.x) yn = sk.y;
-    if (yn >= Hr) { yn = 0; xtn = xt + 1; }
+    if (yn >= Hr) { yn = 0; xtn = xt + 1; }   // (a dead tile's (0, Hr) entry is never entered: dead tiles are trailing, S ends before -- dead_tiles_kernel)
     if (s + 1 < S) issue_row(xtn, yn, (s + 1) & 1);
 
     // candidate of the NEXT iteration: the patch row completed by THIS step

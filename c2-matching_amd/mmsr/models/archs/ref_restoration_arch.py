@@ -256,12 +256,21 @@ class RestorationNet(nn.Module):
             return False
         if self.dyn_agg_restore.has_inner_hooks() or _has_hooks(self.content_extractor):
             return False   # forward hooks on inner modules only fire on the module-by-module path
-        # size limits of the fused kernels (32-bit byte offsets inside one sample: the planar offset/mask planes of the
-        # largest DCN head, 27*dg channels at 4h x 4w, are the first to overflow; C2M_ERR_UNSUPPORTED otherwise):
-        # larger outputs run module by module instead of raising in the middle of the forward
+        # size limit of the fused kernels: 32-bit byte offsets inside ONE sample's planar offset planes [2*9*dg][4h][4w] between the
+        # largest DCN head and the DCNv2 kernel that reads them (csrc/conv3x3.hip C2M_OUT_DCN_HEAD, dcn_v2.hip use_nhwc) --
+        # LR <= 482 x 482 with 8 deformable groups (round 5 counted the mask planes in as well: 394).  Larger inputs run
+        # module by module (correct, on stock convolution kernels) instead of raising in the middle of the forward -- with a
+        # warning, once per module, so that nobody benchmarks the slow path unknowingly.
         h, w = x.shape[2:]
         dg = self.dyn_agg_restore.large_dyn_agg.deformable_groups
-        return 27 * dg * (4 * h) * (4 * w) * 4 < 2 ** 31 - 1
+        if 18 * dg * (4 * h) * (4 * w) * 4 < 2 ** 31 - 1:
+            return True
+        if not getattr(self, "_c2m_warned_size", False):
+            import warnings
+            warnings.warn(f"RestorationNet: LR {h}x{w} is beyond the fused gfx950 path's 32-bit plane offsets (LR <= ~482x482 at "
+                          f"{dg} deformable groups); this forward runs module by module on stock convolution kernels", RuntimeWarning)
+            self._c2m_warned_size = True
+        return False
 
     def _use_train_kernels(self, x, img_ref_feat):
         """Gradients enabled (stage-3 training): the decoder's 3x3 convolutions run forward AND backward on the hand-written

@@ -140,6 +140,32 @@ PY
                   rm -rf $O/abl_$abl
                 done
                 cd $R ;;
+    avail)      cd /tmp; (rocprofv3 --list-avail 2>&1 | grep -o "\b\(TCP\|TA\|TD\|TCC\|SQ\|SQC\|GRBM\|CPC\|SPI\)_[A-Za-z0-9_]*" | sort -u | tr "\n" " ") > $O/pmc_avail.txt 2>&1; cd $R ;;
+    abl_rb)     (for hw in 640 320 160; do for m in 0 64 6 2; do
+                   echo "=== C2M_SPLIT_ABL=$m hw=$hw (64: one store per tile; 6: no halo loads, no split; 2: no halo loads)"
+                   ps=""; [ $m = 0 ] && [ $hw = 640 ] && ps="--persample"
+                   C2M_SPLIT_ABL=$m timeout 200 python scripts/abl_resblock.py --hw $hw $ps 2>&1 | grep "^{"
+                 done; done) > $O/abl_resblock.log 2>&1 ;;
+    pmc_dcn)    cd /tmp
+                i=0
+                for set in "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU" \
+                           "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
+                           "${PMC_SET3:-TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum}" \
+                           "${PMC_SET4:-TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr}" \
+                           "${PMC_SET5:-TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_WAVEFRONTS_sum TD_TD_BUSY_sum}" \
+                           "${PMC_SET6:-TCP_TCC_WRITE_REQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_HIT_sum TCC_MISS_sum}"; do
+                  i=$((i+1))
+                  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $O/pmcd_$i -o c -- python $R/scripts/bench_dcn_nhwc.py --iters 2 > $O/pmcd_$i.log 2>&1
+                  echo "=== dcn forward, pass $i: $set" >> $O/pmc_dcn_c3.txt
+                  python $R/scripts/pmc_kernel.py $O/pmcd_$i dcn_fwd >> $O/pmc_dcn_c3.txt 2>&1
+                  tail -3 $O/pmcd_$i.log | cut -c1-300 >> $O/pmc_dcn_c3.txt
+                  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $O/pmcc_$i -o c -- python $R/scripts/abl_c3.py 16 640 twin > $O/pmcc_$i.log 2>&1
+                  echo "=== first layer (twin), pass $i: $set" >> $O/pmc_dcn_c3.txt
+                  python $R/scripts/pmc_kernel.py $O/pmcc_$i conv3x3_c3 >> $O/pmc_dcn_c3.txt 2>&1
+                  tail -2 $O/pmcc_$i.log | cut -c1-300 >> $O/pmc_dcn_c3.txt
+                  rm -rf $O/pmcd_$i $O/pmcc_$i
+                done
+                cd $R ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac

@@ -424,6 +424,13 @@ def test_conv3x3_split16_domain(ops, dev):
 # <= 3 x, and that is one of the two reasons it is not the default.
 # ---------------------------------------------------------------------------------------------------------------------
 WINO16_ALGOS = ("wino16", "wino16_f23")
+
+
+@pytest.fixture
+def experimental(ops):
+    """Round 6: both no-go kernels moved to csrc/experimental/ and out of the product library (`make EXPERIMENTAL=1` builds them)."""
+    if not ops.experimental_built():
+        pytest.skip("libc2m_hip.so built without EXPERIMENTAL=1 (csrc/experimental/ kernels are not in the product library)")
 WINO16_VS_DIRECT = {"wino16": 3.0, "wino16_f23": 1.5}
 WINO16_CASES = [c for c in CASES + WINO_CASES if c[2] % 64 == 0] + [
     (1, [16], 64, 8, 32, 0, 0),          # one chunk per tile: prologue / first-operand paths only
@@ -438,7 +445,7 @@ WINO16_CASES = [c for c in CASES + WINO_CASES if c[2] % 64 == 0] + [
 
 @pytest.mark.parametrize("algo", WINO16_ALGOS)
 @pytest.mark.parametrize("case", WINO16_CASES)
-def test_conv3x3_wino16_matches_fp64_conv2d(ops, dev, case, algo):
+def test_conv3x3_wino16_matches_fp64_conv2d(experimental, ops, dev, case, algo):
     B, cins, Cout, H, W, act, nres = case
     xs = [_cl(_rand((B, c, H, W), dev, 410 + k)) for k, c in enumerate(cins)]
     w = _rand((Cout, sum(cins), 3, 3), dev, 420, 1.0 / np.sqrt(9 * sum(cins)))
@@ -457,7 +464,7 @@ def test_conv3x3_wino16_matches_fp64_conv2d(ops, dev, case, algo):
         assert torch.equal(auto, got)
 
 
-def test_conv3x3_wino16_is_as_accurate_as_the_fp32_mfma_kernel(ops, dev):
+def test_conv3x3_wino16_is_as_accurate_as_the_fp32_mfma_kernel(experimental, ops, dev):
     """Same criterion as the direct f16 x 2 kernel's: distance from float64 <= 1.5 x the exact-fp32-MFMA kernel's, in the
     maximum and in the root-mean-square sense, on K = 9 * 256 products per output (N(0,1) inputs) and on non-negative
     (post-ReLU-like) inputs, where a Winograd transform's intermediate magnitudes are least favourable."""
@@ -480,7 +487,7 @@ def test_conv3x3_wino16_is_as_accurate_as_the_fp32_mfma_kernel(ops, dev):
 
 @pytest.mark.parametrize("algo", WINO16_ALGOS)
 @pytest.mark.parametrize("xs_,ws_", [(1e-3, 1.0), (1e3, 1.0), (1.0, 1e-6), (1.0, 1e5), (3e-3, 2e-4), (250.0, 37.0)])
-def test_conv3x3_wino16_scales(ops, dev, algo, xs_, ws_):
+def test_conv3x3_wino16_scales(experimental, ops, dev, algo, xs_, ws_):
     """Away from unit scale (activations 1e-3 ... 1e3, weights of any magnitude) the RELATIVE accuracy of the unit-scale case holds."""
     x = _cl(_rand((1, 64, 16, 40), dev, 450)) * xs_
     w, b = _rand((64, 64, 3, 3), dev, 451, 1.0 / 24.0) * ws_, _rand((64,), dev, 452) * (xs_ * ws_)
@@ -492,7 +499,7 @@ def test_conv3x3_wino16_scales(ops, dev, algo, xs_, ws_):
 
 
 @pytest.mark.parametrize("algo", WINO16_ALGOS)
-def test_conv3x3_wino16_domain_and_range_flag(ops, dev, algo):
+def test_conv3x3_wino16_domain_and_range_flag(experimental, ops, dev, algo):
     """Domain |x| < 26200 (F(4,3)) / 32760 (F(2,3)): beyond it the kernel raises the range flag (the guarded module forwards then
     recompute on bf16 x 3) -- below it, mixed magnitudes 1e-6 ... 3e3 keep the tolerance; zero weights give exactly the bias."""
     x = _cl(_rand((1, 32, 8, 32), dev, 460))
@@ -516,7 +523,7 @@ def test_conv3x3_wino16_domain_and_range_flag(ops, dev, algo):
 
 
 @pytest.mark.parametrize("algo", WINO16_ALGOS)
-def test_conv3x3_wino16_full_size_body_conv(ops, dev, algo):
+def test_conv3x3_wino16_full_size_body_conv(experimental, ops, dev, algo):
     """configs[2]'s own body layer: 64 -> 64 @640^2, B = 16 (chip-filling: 14 080 tiles on 256 workgroups, 55 tiles per stream),
     ReLU + residual; a sub-block of the LAST sample against float64, the whole tensor against the direct f16 x 2 kernel, and
     bit-identical results across repeated launches."""
@@ -912,7 +919,7 @@ def test_f16_range_guard_switches_a_module_to_bf16x3(ops, dev):
         assert all(bool(torch.isfinite(v).all()) for v in small.values())
 
 
-def test_loader_matrix_wave_kernel_opt_in(dev):
+def test_loader_matrix_wave_kernel_opt_in(experimental, dev):
     """csrc/conv3x3_pc.hip ($C2M_CONV_PC=1: the f16 x 2 arithmetic with loader and matrix waves, DESIGN.md 6.10 -- measured
     slower than the split kernel, kept opt-in): ragged, multi-chunk and chip-filling 64-cout layers against float64 and the
     fp32-MFMA kernel, bit-identical repeats.  A process of its own: the switch is read once per process."""

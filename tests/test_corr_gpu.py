@@ -321,6 +321,62 @@ def test_prefilter_equals_exact_sweep(env, dev, C, hq, hr, B):
         assert np.array_equal(r[1][0][b], oi) and np.array_equal(r[1][1][b], ov)
 
 
+def test_all_duplicate_middle_band_keeps_later_tiles_live(env, dev):
+    """`dead_tiles_kernel` encodes a dead x-tile as (0, Hr) in the duplicate-row table, and both sweeps only honour
+    such an entry on a TRAILING set of tiles (they subtract it from the step count up front).  The invariant is by construction --
+    a tile is dead iff its first patch column lies beyond the LAST column that holds a non-duplicate patch -- so a band of
+    all-duplicate patch columns in the MIDDLE of the ref map (x-tiles 1 .. 2 of 4 entirely constant) must leave the tiles behind it
+    live: full maps, values included, equal the oracle's on both implementations, and the table shows no dead tile but the
+    trailing one."""
+    ops, oracle, synth = env
+    C, hq, hr = 256, (18, 22), (24, 120)                       # four x-tiles of 28 patch columns (+ a ragged fifth)
+    fi = oracle.feature_normalize(synth.gaussish((C,) + hq, 510))
+    fr = oracle.feature_normalize(synth.gaussish((C,) + hr, 511))
+    fr[:, :, 26:88] = fr[:, :, 26:27]                           # columns 26 .. 87 constant along x: patch columns 27 .. 85 repeat their left neighbour
+    fr[:, :, 26:88] = fr[:, 3:4, 26:88]                         # ... and along y: every patch in x-tiles 1, 2 repeats its upper neighbour too
+    fr[:, :, 110:] = fr[:, 5:6, 110:111]                        # a constant trailing band (last live patch column 110 < 112): x-tile 4 IS dead
+    r = _both_modes(ops, _t(fi[None], dev), _t(fr[None], dev))
+    oi, ov = oracle.feature_match_index(fi, fr, 3, 1, 1, True, True)
+    for mode in (1, 0):
+        assert np.array_equal(r[mode][0][0], oi) and np.array_equal(r[mode][1][0], ov), mode
+    assert int(r[1][2]["flags"][0]) == 0
+    with ops.record_corr_skip_table():
+        ops.feature_match_index_batched(_t(fi[None], dev), _t(fr[None], dev), 3, 1, 1, True, True)
+        skip = ops.last_corr_skip_table().cpu().numpy()[0]     # [x-tile][2]
+    dead = [(int(a) == 0 and int(b) == hr[0]) for a, b in skip]
+    assert dead[-1] and not any(dead[:-1]), skip               # only the trailing tile; the all-duplicate middle tiles are swept
+    assert (oi % (hr[1] - 2)).max() >= 86                       # some query really picked a patch column behind the middle band
+
+
+def test_filter_mode_reaches_launches_from_worker_threads(env, dev):
+    """the library's A/B switch is thread_local; `with ops.corr_filter_mode(0)` opened on the main thread must still
+    govern a launch made from a worker thread (nn.DataParallel replicas launch from such threads) -- the op wrapper re-applies
+    the recorded mode on the launching thread.  Observed through the kernel names the profiler records."""
+    import threading
+    import c2m_amd
+    ops, oracle, synth = env
+    fi = _t(oracle.feature_normalize(synth.gaussish((256, 20, 20), 71))[None], dev)
+    fr = _t(oracle.feature_normalize(synth.gaussish((256, 24, 24), 72))[None], dev)
+    seen = {}
+
+    def launch(tag):
+        with torch.cuda.device(dev):
+            ops.feature_match_index_batched(fi, fr, 3, 1, 1, True, True)
+            torch.cuda.synchronize()
+
+    for tag, mode in (("exact", 0), ("filter", 1)):
+        c2m_amd.profile_enable(True)
+        c2m_amd.profile_collect()
+        with ops.corr_filter_mode(mode):
+            th = threading.Thread(target=launch, args=(tag,))
+            th.start()
+            th.join()
+        seen[tag] = {n for n, _ in c2m_amd.profile_collect()}
+        c2m_amd.profile_enable(False)
+    assert "corr_argmax_mfma" in seen["exact"] and "corr_filter" not in seen["exact"], seen
+    assert "corr_filter" in seen["filter"], seen
+
+
 def test_prefilter_leaves_its_domain_through_the_exact_sweep(env, dev):
     """|x| >= 3.99 (f16 pieces would overflow), a degenerate all-zero ref patch (1 / (|r| + 1e-5) > 2) and a NaN each raise the
     device flag; the result is then the exact sweep's -- the oracle's -- without a host round trip."""

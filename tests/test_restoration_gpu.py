@@ -295,6 +295,90 @@ def test_cfg3_full_forward_at_batch16(dev):
     assert float((sr1[0] - sr[15]).abs().max()) < 1e-3
 
 
+def test_image_boundary_parity_full_size_pair_vs_cpu_chain(dev):
+    """North_star's tolerance at the IMAGE boundary as an assertion, one full-size configs[2] pair:
+    the HIP path (extractor -> correlation -> pre-offsets -> VGG taps -> RestorationNet, default f16 x 2 arithmetic) against
+    oracle/cpu_chain.py -- stock torch-CPU convolutions, the reference's conv2d-filter correlation (ref_map_util.py:26-86), the C
+    oracle for pre-offsets and DCNv2.
+      * index map: the two extractor implementations (hand-written f16 x 2 pieces vs oneDNN) may resolve an fp32 near-tie
+        differently; every flip must BE one (float64 margin of the two candidates < 1e-6; measured ~1e-7), and there are at
+        most 4 of 24 964 (measured 0 - 2);
+      * SR image: given the GPU's index map the CPU decoder agrees to <= 1e-3 on EVERY pixel of the 640 x 640 image (measured
+        ~1.2e-7): a regression that moved the decoder at full size only would fail here, not just show up in a bench line.
+    ~15 s of host time on the GPU box's cores."""
+    import c2m_oracle as oracle
+    import cpu_chain
+    oracle.set_num_threads(min(64, __import__("os").cpu_count() or 1))
+    ext, mp, g = _build_chain(dev)
+    lq, up, ref = _synthetic_pairs(3, 160, dev, 4700)
+    with torch.no_grad():
+        feats = ext(up, ref)
+        pre, ref_feat = mp(feats, ref)
+        assert g._use_fused(lq, pre, ref_feat)
+        sr = g(lq, pre, ref_feat)
+    b = 2                                                  # (not sample 0: batch strides are part of what is checked)
+    idx_gpu = pre.max_idx[b:b + 1].cpu().numpy()
+    sr_cpu, idx_cpu, f = cpu_chain.full_forward_cpu(ext, mp, g, lq[b:b + 1], up[b:b + 1], ref[b:b + 1], True, None, cond_idx=idx_gpu)
+    flips = cpu_chain.mismatch_margins(f["dense_features1"][0], f["dense_features2"][0], idx_gpu[0], idx_cpu[0])
+    assert len(flips) <= 4, flips
+    assert all(abs(m[3]) < 1e-6 for m in flips), flips
+    d = (sr[b].cpu() - f["sr_given_idx"][0]).abs()
+    assert tuple(d.shape) == (3, 640, 640)
+    assert float(d.max()) <= 1e-3, float(d.max())
+    assert float(d.max()) <= 5e-5, f"decoder drifted from the CPU chain: {float(d.max())} (north_star allows 1e-3; measured 1.2e-7)"
+    if not flips:                                          # same index map -> the unconditional images agree too
+        assert float((sr[b].cpu() - sr_cpu[0]).abs().max()) <= 1e-3
+
+
+def _random_restoration_inputs(h, dev, seed):
+    """RestorationNet inputs of LR size h x h without running the extractor: a random LR image, a lazy PreOffsets over a random
+    (valid) index map, N(0,1)-ish Ref features of the three tap shapes."""
+    import synth
+    from mmsr.models.archs.corres_generation_arch import PreOffsets
+    g_ = torch.Generator(device="cpu").manual_seed(seed)
+    lq = torch.from_numpy(synth.uniform((1, 3, h, h), seed, 0.0, 1.0)).to(dev)
+    idx = torch.randint(0, (h - 2) * (h - 2), (1, h - 2, h - 2), generator=g_, dtype=torch.int64).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(seed + 1)
+    feats = {k: torch.randn((1, c, s_ * h, s_ * h), generator=gen, device=dev) for k, c, s_ in
+             (("relu3_1", 256, 1), ("relu2_1", 128, 2), ("relu1_1", 64, 4))}
+    return lq, PreOffsets(idx, h, h), feats
+
+
+def test_fused_path_size_limit_and_warning(dev):
+    """the fused path's size limit is the 32-bit byte offset inside one sample's planar offset planes
+    (ref_restoration_arch.py `_use_fused`): LR <= 482 x 482 at 8 deformable groups (round 5 stopped at 394 because it counted the
+    mask planes into the same range).  (1) LR 400 x 400 -- beyond the old limit, the size class of WR-SR references -- stays on
+    the hand-written kernels and agrees with the module-by-module path (stock convolutions + the NCHW DCNv2 operator, same
+    pre-offsets) to north_star's 1e-3 (asserted at 1e-4: both are fp32-equivalent).  (2) Beyond the limit the net declines
+    the fused path WITH a warning, once."""
+    import warnings
+    from mmsr.models.archs.ref_restoration_arch import RestorationNet
+    torch.manual_seed(5)
+    net = RestorationNet(64, 16, 8).eval().to(dev)
+    for stage in ("small", "medium", "large"):   # live offset heads
+        torch.nn.init.normal_(getattr(net.dyn_agg_restore, f"{stage}_dyn_agg").conv_offset_mask.weight, std=0.01)
+    lq, pre, feats = _random_restoration_inputs(400, dev, 9100)
+    with torch.no_grad():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # no size warning at LR 400
+            assert net._use_fused(lq, pre, feats)
+            sr = net(lq, pre, feats)
+        net.allow_fused = False
+        want = net(lq, pre, feats)
+        net.allow_fused = True
+    assert tuple(sr.shape) == (1, 3, 1600, 1600) and bool(torch.isfinite(sr).all())
+    err = float((sr - want).abs().max())
+    assert err < 1e-4, err
+    big = torch.zeros((1, 3, 484, 484), device=dev)
+    tiny = {k: v[:, :, :8, :8] for k, v in feats.items()}       # (_use_fused looks at dtypes / channel counts only)
+    with pytest.warns(RuntimeWarning, match="module by module"):
+        assert not net._use_fused(big, pre, tiny)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                           # once per module
+        assert not net._use_fused(big, pre, tiny)
+    assert net._use_fused(torch.zeros((1, 3, 482, 482), device=dev), pre, tiny)
+
+
 def test_cfg3_chain_160_batch2(dev):
     """BASELINE configs[2] shape at B=2: extractor -> correlation/index map -> pre-offsets -> VGG taps -> RestorationNet at
     LR 160x160 / Ref 500x500 padded to 640x640.  Sample 1 (not 0: batch indexing) is checked against the oracle: index
