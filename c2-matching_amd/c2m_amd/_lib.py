@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ($C2M_LIB: another build of the same library -- kernel A/B measurements; the product path is the in-tree build)
 LIB_PATH = os.environ.get("C2M_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libc2m_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _lib = None
@@ -32,6 +32,14 @@ class Conv3x3Desc(ctypes.Structure):
                 ("abs_sum", _vp), ("algo", _i), ("cout_offset", _i), ("cout_total", _i),
                 ("out2", _vp), ("out2_row_pitch", _i), ("out2_plane_pitch", ctypes.c_longlong),
                 ("out2_img_pitch", ctypes.c_longlong), ("range_flag", _vp), ("io_flags", ctypes.c_int)]
+
+
+class ResBlockDesc(ctypes.Structure):
+    """c2m_resblock3x3_desc of include/c2m_hip.h"""
+    _fields_ = [("B", _i), ("H", _i), ("W", _i), ("C", _i), ("x", _vp), ("x_pix_pitch", _i), ("x_row_pitch", _i),
+                ("x_img_pitch", ctypes.c_longlong), ("out", _vp), ("out_pix_pitch", _i), ("out_row_pitch", _i),
+                ("out_img_pitch", ctypes.c_longlong), ("res2", _vp), ("wr1", _vp), ("wr2", _vp), ("bias1", _vp), ("bias2", _vp),
+                ("range_flag", _vp)]
 
 
 class C2MError(RuntimeError):
@@ -95,6 +103,10 @@ def _declare(L):
     L.c2m_conv3x3_wgrad_workspace_bytes.argtypes = [_i] * 5
     L.c2m_conv3x3_wgrad_f32.argtypes = [_vp, ctypes.POINTER(ConvSrc), _i, _vp, _i, _i, ctypes.c_longlong] + [_i] * 5 + [_vp, _vp, _sz]
     L.c2m_conv3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(Conv3x3Desc)]
+    L.c2m_resblock3x3_nhwc_f32.argtypes = [_vp, ctypes.POINTER(ResBlockDesc)]
+    L.c2m_resblock3x3_nhwc_f32.restype = _i
+    L.c2m_resblock3x3_supported.argtypes = [_i, _i, _i]
+    L.c2m_resblock3x3_supported.restype = _i
     L.c2m_index_to_flow_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp]
 
 

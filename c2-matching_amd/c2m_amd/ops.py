@@ -841,6 +841,66 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     return out
 
 
+# C2M_RESBLOCK: "auto" (default) -- the fused inference bodies run a whole ResidualBlockNoBN (arch_util.py:80-136) as ONE launch
+# (csrc/conv3x3_resblock.hip) where the f16 x 2 flavour is active and the map has at least C2M_RESBLOCK_MINPIX pixels; "0" -- two
+# launches per block (conv3x3 twice) everywhere; "1" -- wherever the kernel supports the shape.
+_RESBLOCK = _os.environ.get("C2M_RESBLOCK", "auto")
+_RESBLOCK_MINPIX = int(_os.environ.get("C2M_RESBLOCK_MINPIX", str(300 * 300)))
+
+
+def resblock3x3_ok(x, w1, w2, res2=None):
+    """True if `resblock3x3` takes these tensors: fp32 channels-last GPU activations, two [64, 64, 3, 3] weights."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64 and x.stride(1) == 1 and
+            tuple(w1.shape) == (64, 64, 3, 3) and tuple(w2.shape) == (64, 64, 3, 3) and
+            (res2 is None or (res2.dtype == torch.float32 and res2.shape == x.shape and res2.stride() == x.stride())))
+
+
+def resblock3x3_wanted(x):
+    """The policy of the fused bodies (ref_restoration_arch._fused_body): f16 x 2 active for this thread's auto calls, map large enough."""
+    if _RESBLOCK == "0" or _SPLIT == "0" or not _f16x2_auto():
+        return False
+    return _RESBLOCK == "1" or x.shape[2] * x.shape[3] >= _RESBLOCK_MINPIX
+
+
+def resblock3x3(x, w1, b1, w2, b2, res2=None, out=None):
+    """out = x + conv2(relu(conv1(x) + b1)) + b2 (+ res2): a ResidualBlockNoBN (arch_util.py:128-136, res_scale 1) in ONE launch
+    on the f16 x 2 arithmetic (c2m_resblock3x3_nhwc_f32: the intermediate tensor stays in LDS, x is read once, the identity is
+    rebuilt from x's two f16 pieces -- equal to two conv3x3(algo="split16") launches up to that rounding, |d| <= 2^-22 |x|).
+    x: channels_last [B,64,H,W] fp32; domain as algo="split16" (range flag of the enclosing guard / the device)."""
+    if not resblock3x3_ok(x, w1, w2, res2):
+        raise _lib.C2MError("resblock3x3: channels_last float32 GPU tensor [B,64,H,W], weights [64,64,3,3]")
+    B, _, H, W = x.shape
+    dev = x.device
+    wr1, wr2 = _wcache.get(w1, wino=6), _wcache.get(w2, wino=6)
+    if out is None:
+        out = empty_nhwc(B, 64, H, W, dev)
+    if out.data_ptr() == x.data_ptr():
+        raise _lib.C2MError("resblock3x3: out may not alias x")
+    xs, o = _nhwc_src(x, "x"), _nhwc_src(out, "out")
+    d = _lib.ResBlockDesc()
+    d.B, d.H, d.W, d.C = B, H, W, 64
+    d.x, d.x_pix_pitch, d.x_row_pitch, d.x_img_pitch = xs.ptr, xs.pix_pitch, xs.row_pitch, xs.img_pitch
+    d.out, d.out_pix_pitch, d.out_row_pitch, d.out_img_pitch = out.data_ptr(), o.pix_pitch, o.row_pitch, o.img_pitch
+    if res2 is not None:
+        r = _nhwc_src(res2, "res2")
+        if (r.pix_pitch, r.row_pitch, r.img_pitch) != (o.pix_pitch, o.row_pitch, o.img_pitch):
+            raise _lib.C2MError("resblock3x3: res2 must have the geometry of the output")
+        d.res2 = res2.data_ptr()
+    d.wr1, d.wr2 = wr1.data_ptr(), wr2.data_ptr()
+    b1 = _dev_f32(b1.detach(), "bias1") if b1 is not None else None
+    b2 = _dev_f32(b2.detach(), "bias2") if b2 is not None else None
+    d.bias1 = b1.data_ptr() if b1 is not None else None
+    d.bias2 = b2.data_ptr() if b2 is not None else None
+    d.range_flag = _range_flag(dev).data_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().c2m_resblock3x3_nhwc_f32(_stream(), d), "c2m_resblock3x3_nhwc_f32")
+    if _ConvFlops.enabled:
+        alg = 2 * 2.0 * 64 * 9 * 64 * H * W * B
+        steps = B * ((W + 29) // 30) * ((H + 2 + 7) // 8)          # strips x steps of 8 rows x 32 MFMA columns, both convolutions
+        _ConvFlops.add("resblock_split_f16x2", alg, steps * 2 * 3.0 * 2.0 * 64 * 9 * 64 * 256)
+    return out
+
+
 def conv3x3_dgrad(grad_out, weight):
     """Data gradient of conv3x3: grad_out channels-last [B,Cout,H,W], weight [Cout,Cin,3,3] -> dX channels-last [B,Cin,H,W]
     = conv3x3(grad_out, W') with W'[ci][co][dy][dx] = W[co][ci][2-dy][2-dx], on the split-bf16 kernel (fp32-accurate)."""

@@ -66,7 +66,7 @@ extern "C" int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int*
   return C2M_OK;
 }
 
-extern "C" int c2m_abi_version(void) { return 2; }
+extern "C" int c2m_abi_version(void) { return 3; }
 
 extern "C" const char* c2m_status_string(int status) {
   switch (status) {

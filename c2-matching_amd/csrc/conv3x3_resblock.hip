@@ -1,0 +1,672 @@
+// conv3x3_resblock.hip -- ONE launch for a whole ResidualBlockNoBN of the decoder bodies (arch_util.py:80-136:
+//   out = x + conv2(relu(conv1(x)))   [+ res2: the stage skip of ref_restoration_arch.py:153,166,179 on a body's last block]
+// 64 -> 64 channels, fp32 channels-last tensors, the f16 x 2 arithmetic of conv3x3_split.hip (three f16 MFMA products per fp32
+// product sum, per-tensor-scaled weights, domain |x| < 65520 reported through range_flag).
+//
+// Why: the two-launch path moves five tensor passes per block (x in, t out, t in, x as residual in, y out) where two suffice, and
+// on this chip that traffic is paid for next to the matrix time, not under it (profiles/r06_resblock_ablation.log: the residual
+// read alone is 0.29 of a 1.61 ms launch at 640^2, B = 16).  Here t never leaves the CU and x is read once.
+//
+// Mapping -- a SLIDING WINDOW down a column strip, so that no row of t is computed twice:
+//   * a strip = 30 output columns (the 32 MFMA columns of a pixel tile are the t columns x0-1 .. x0+30: conv2 needs one t column
+//     left and right of its outputs); a STEP = 8 rows.  Step s of a strip computes
+//         conv1:  t rows  T(s) = [8s-1, 8s+7)   from the 34 x 10 halo tile of x at rows [8s-2, 8s+8)   (exactly the split kernel's tile)
+//         conv2:  out rows O(s) = [8s-2, 8s+6)   from t rows [8s-3, 8s+7) = the last two rows of T(s-1) + T(s)
+//     t lives in LDS as the f16 x 2 B-operand planes conv2 multiplies -- a RING of 10 rows x 32 columns x 64 channels x 2 planes
+//     (80 KiB): step s overwrites the eight rows step s-1 has finished with.  t outside the image is zero (conv2's padding).
+//   * the residual never comes back from memory: x at an output pixel is the B operand of conv1's tap (0, 1) of the same lane, so
+//     while chunk c's planes are resident the wave reads its own centre pixels back (8-byte LDS reads), rebuilds
+//     x~ = x0 + 2^-11 x1' (the two f16 pieces: |x - x~| <= 2^-22 |x|, one to two ulp) and INITIALISES conv2's accumulators
+//     with S2 * x~ (S2 = conv2's weight scale, a power of two): out = (S2 x~ + sum) / S2 + bias2.
+//   * one workgroup = 4 waves = ONE per SIMD, one workgroup per CU (the ring + two x plane buffers + a 3-slot weight ring fill
+//     the 160 KiB of LDS), up to 512 registers per lane: 64 accumulators for conv1, 64 for conv2.  Wave w owns rows 2w, 2w+1 of
+//     a step in both convolutions (2 pixel tiles x 2 channel tiles, as in the split kernel).
+//   * a step is EIGHT 16-channel chunks through one pipeline: chunks 0-3 multiply x planes (conv1; the halo tile arrives as
+//     fp32 in registers two chunks ahead and is split into planes inside the MFMA groups, as in the split kernel), chunks 4-7
+//     multiply ring planes (conv2).  The weight stream is 24 units (kernel rows) per step -- 12 of conv1's image, 12 of conv2's
+//     (the split kernel's cached f16 x 2 images, unchanged) -- through the same 3-slot LDS-DMA ring, two units ahead, one barrier
+//     per unit.  conv1's epilogue (bias, ReLU, zero outside the image, f16 split, ring store) is cut into four 16-channel parts:
+//     part 0 sits between the phases, parts 1-3 ride in the MFMA groups of conv2's chunks 0-2 (chunk k only reads part k).
+//   * work = B x strips x steps, cut into one contiguous range per workgroup (256 workgroups, XCD-contiguous); a range that
+//     starts inside a strip runs the step before it without storing (it needs that step's last two t rows): < 1 % extra.
+// Overheads against the two-launch path: 32 / 30 MFMA columns, strips x 30 >= W, one priming step per workgroup, steps x 8 >= H + 2.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "c2m_common.h"
+#include "conv3x3_shared.h"
+
+namespace c2m {
+namespace conv {
+namespace rb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));   // 16 raw operand bytes (the asm wrappers' register type)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 16;                          // input channels per chunk = K of v_mfma_f32_32x32x16_f16
+constexpr int TWX = 32, THY = 8;                // t tile of a step
+constexpr int OW = 30;                          // valid output columns of a strip
+constexpr int HWc = TWX + 2, HHr = THY + 2;     // x halo tile 34 x 10
+constexpr int NPIX = HWc * HHr;                 // 340
+constexpr int NRAW_W = 6;                       // raw 16-byte pieces per wave and chunk (24 slots of 64 pieces; 22 carry pixels)
+constexpr int HALFB = NPIX * 16;                // one (plane, k half) slab of an x plane buffer
+constexpr int PLB = 2 * 2 * HALFB;              // one x plane buffer: [plane 2][k half 2][340 pixels][8 f16]
+static_assert(HALFB % 128 == 64, "bank phase of the second k half (conv3x3_split.hip)");
+constexpr int RSLOT = 10;                       // ring rows
+constexpr int ROWB = TWX * 16;                  // one ring row of one (chunk, plane, k half): 32 pixels x 8 f16
+constexpr int KHB = RSLOT * ROWB;               // (chunk, plane, k half) slab
+constexpr int PLNB = 2 * KHB;                   // (chunk, plane)
+constexpr int CHB = 2 * PLNB;                   // one 16-channel chunk of t
+constexpr int RINGB = 4 * CHB;                  // 81 920
+constexpr int NRING = 3;                        // weight ring slots
+constexpr int WTAP = 2 * 2 * 1024;              // one tap's weight image: [image wA, w1][mt 2][k half 2][32 rows][16 B]
+constexpr int WUNIT = 3 * WTAP;                 // one kernel row
+constexpr int NWI = WUNIT / 1024, NW_W = NWI / 4;   // 12 LDS-DMA instructions per unit, 3 per wave
+constexpr int WIMG = 12 * WUNIT;                // one convolution's image (64 -> 64): 147 456 bytes, 1/S behind it
+constexpr int LDS_BYTES = 2 * PLB + 16 + RINGB + 16 + NRING * WUNIT + 512;
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+constexpr float F16_LO_SCALE = 2048.0f;
+
+struct Params {
+  Src x;                      // input, 64 channels
+  float* out;
+  int out_pix_pitch, out_row_pitch;
+  long long out_img_pitch;
+  const float* res2;          // second residual with out's geometry, or nullptr
+  const void* wr1;            // conv1 / conv2: f16 x 2 images of c2m_conv3x3_relayout_split_f32(pieces = 2), 1/S behind each
+  const void* wr2;
+  const float* bias1;         // [64] or nullptr
+  const float* bias2;
+  int B, H, W, nstrips, nsteps;
+  int total;                  // B * nstrips * nsteps
+  int* range_flag;
+  int abl;                    // $C2M_RB_ABLR: timing-only runtime ablations (WRONG results): 1 no output stores, 16 no output epilogue, 64 no conv1 epilogue
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read128(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void lds_read64(u32x2& d, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void lds_write64(unsigned addr, const u32x2 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void buf_load128f(f32x4& d, unsigned voff, const i32x4 rsrc, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// two round-to-nearest f16 pieces of four fp32 values: p0 = rne_f16(v), p1 = rne_f16(2^11 (v - p0))   (conv3x3_split.hip)
+__device__ __forceinline__ void split2_f16(const f32x4 v, u32x2& p0, u32x2& p1) {
+  const f16x4 h0 = __builtin_convertvector(v, f16x4);
+  const f32x4 r = (v - __builtin_convertvector(h0, f32x4)) * F16_LO_SCALE;
+  const f16x4 h1 = __builtin_convertvector(r, f16x4);
+  p0 = __builtin_bit_cast(u32x2, h0);
+  p1 = __builtin_bit_cast(u32x2, h1);
+}
+
+#ifndef C2M_RB_ABL
+#define C2M_RB_ABL 0   // timing-only ablations (WRONG results), compile time: 1 no output stores, 2 no MFMAs, 4 no x loads, 8 no unit-end
+                       // waits / barriers, 16 no output epilogue at all, 32 no operand wait in front of a unit's first tap, 64 no conv1 epilogue
+#endif
+
+__global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
+  constexpr int MT = 2, NT = 2, NPX = 2, NPW = 2, NG = 3;
+  constexpr int NLA = NPW * MT, NLB = NPX * NT;            // operand reads per tap: 4 A + 4 B
+  constexpr int LPG = (NLA + NLB + 1) / 2;                  // ... issued in the first two MFMA groups of the tap before
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  // [x planes: two buffers | 16 | t ring | 16 | weight ring | bias1, bias2]; dead LDS-DMA pieces (past the end of the stream)
+  // land in x plane buffer 1, which nobody reads by then
+  const unsigned pl_base = lds0, ring = lds0 + 2 * PLB + 16, w_base = ring + RINGB + 16, bias_lds = w_base + NRING * WUNIT,
+                 dummy = pl_base + PLB;
+
+  const int tid = threadIdx.x, l = tid & 63, hi = l >> 5, j = l & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- this workgroup's range of steps: [g0, g1) of B x strips x steps, one step earlier (without stores) if it starts
+  // inside a strip
+  const int nwg = gridDim.x, wg = xcd_remap(blockIdx.x, nwg);
+  int g0 = (int)((long long)p.total * wg / nwg);
+  const int g1 = (int)((long long)p.total * (wg + 1) / nwg);
+  if (g1 <= g0) return;
+  struct Cur { int b, strip, s; };
+  Cur c0;
+  c0.s = g0 % p.nsteps;
+  c0.strip = (g0 / p.nsteps) % p.nstrips;
+  c0.b = g0 / (p.nsteps * p.nstrips);
+  const bool prime = c0.s > 0;
+  if (prime) { --g0; --c0.s; }
+  const int nst = g1 - g0;        // steps this workgroup runs
+  const int G = 4 * nst;          // x chunks of its stream
+  const int UTOT = 24 * nst;      // weight units
+  auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
+    if (++c.s == p.nsteps) {
+      c.s = 0;
+      if (++c.strip == p.nstrips) { c.strip = 0; ++c.b; }
+    }
+  };
+  Cur dma_cur = c0, epi_cur = c0;
+
+  // ---- weights: unit wu of a step (0 .. 11: conv1's kernel rows, chunk-major; 12 .. 23: conv2's) streams by LDS-DMA into the
+  // ring, two units ahead; wave w moves instructions [3w, 3w + 3) of a unit
+  const unsigned wvoff = (wv * NW_W * 64 + l) * 16;
+  int wsoff = 0;          // byte offset, inside its image, of the unit the NEXT issue fetches
+  int wsecond = 0;        // ... and whether that image is conv2's
+  auto issue_w_piece = [&](unsigned slot_off, int i, bool live) __attribute__((always_inline)) {
+    const unsigned dst = live ? w_base + slot_off + (wv * NW_W + i) * 1024 : dummy;
+    // (scalar selects, no branch; readfirstlane: the compiler must see a uniform descriptor or it wraps the DMA in a waterfall loop)
+    const unsigned long long wa = (unsigned long long)(uintptr_t)(wsecond ? p.wr2 : p.wr1);
+    const unsigned wlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa), whi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32));
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)whi << 32) | wlo)), (unsigned)WIMG);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, wvoff, wsoff + i * 1024, 0, 0);
+  };
+  auto issue_w_done = [&](bool live) __attribute__((always_inline)) {
+    const int ns = wsoff + WUNIT;
+    const int wrap = ns == WIMG ? 1 : 0;
+    wsoff = live ? (wrap ? 0 : ns) : wsoff;
+    wsecond = live ? (wsecond ^ wrap) : wsecond;
+  };
+
+  // ---- x halo tile: 24 slots of 64 pieces (pixel, 4 fp32 channels); slot r of wave wv = pieces [64 (wv + 4r), +64)
+  int dma_c = 0;   // chunk (inside its step) the next issue_in_begin() fetches
+  unsigned ivoff[NRAW_W];
+  int slotc[NRAW_W];   // ry | rx << 8 | quad << 16 | valid << 24
+#pragma unroll
+  for (int sl = 0; sl < NRAW_W; ++sl) {
+    const int n = wv + 4 * sl, pix = 16 * n + (l >> 2);
+    const int ry = pix / HWc, rx = pix - ry * HWc;
+    slotc[sl] = ry | (rx << 8) | ((l & 3) << 16) | (pix < NPIX ? (1 << 24) : 0);
+  }
+  i32x4 rs0 = {0, 0, 0, 0x00020000};
+  int in_soff = 0;
+  auto issue_in_begin = [&]() __attribute__((always_inline)) {   // the next chunk of the workgroup's x stream
+    const int cc = dma_c;
+    if (++dma_c == 4) dma_c = 0;
+    if (cc == 0) {
+      const int iy0 = 8 * dma_cur.s - 1, ix0 = OW * dma_cur.strip - 1;   // t tile origin; the halo tile starts one up / left
+      const unsigned bytes = (unsigned)((p.H - 1) * p.x.row_pitch + (p.W - 1) * p.x.pix_pitch + 64) * 4u;
+      rs0 = make_rsrc_words(p.x.ptr + (long long)dma_cur.b * p.x.img_pitch, bytes);
+      cur_next(dma_cur);
+#pragma unroll
+      for (int sl = 0; sl < NRAW_W; ++sl) {
+        const int c = slotc[sl];
+        const int iy = iy0 - 1 + (c & 0xff), ix = ix0 - 1 + ((c >> 8) & 0xff);
+        // (an invalid lane's offset gets bit 31 set, i.e. lies beyond any num_records; valid offsets are < 2^31: host check)
+        const unsigned bad = ((c >> 24) != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? 0u : 1u;
+        ivoff[sl] = ((unsigned)(iy * p.x.row_pitch + ix * p.x.pix_pitch + 4 * ((c >> 16) & 3)) * 4u) | (bad << 31);
+      }
+    }
+    in_soff = cc * KC * 4;
+  };
+  f32x4 rawr[NRAW_W];
+  i32x4 rs_cur = {0, 0, 0, 0x00020000};
+  auto set_chunk_rsrc = [&](bool live) __attribute__((always_inline)) {
+    rs_cur[0] = rs0[0];
+    rs_cur[1] = rs0[1];
+    rs_cur[2] = (live && !(C2M_RB_ABL & 4)) ? rs0[2] : 0;   // zero records: every lane out of range -> zeros, no memory traffic
+    rs_cur[3] = 0x00020000;
+  };
+  auto issue_in_piece = [&](auto slc) __attribute__((always_inline)) {
+    constexpr int sl = decltype(slc)::value;
+    buf_load128f(rawr[sl], ivoff[sl], rs_cur, in_soff);
+  };
+
+  // ---- split of the wave's own raw pieces into the f16 planes (conv3x3_split.hip: round r = piece 64 (wv + 4r) + l)
+  const unsigned cdst = pl_base + ((l >> 1) & 1) * HALFB + (wv * 16 + (l >> 2)) * 16 + (l & 1) * 8;
+  u32x2 cq[2];
+  float amax = 0.0f;   // largest |activation| this lane has split: x and t (domain check, Params::range_flag)
+  auto conv_split = [&](const f32x4 v) __attribute__((always_inline)) {
+    split2_f16(v, cq[0], cq[1]);
+    // (asm volatile: must read the raw registers BEFORE the volatile asm that re-loads them is issued -- conv3x3_split.hip)
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
+                 : "+v"(amax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  };
+  const bool last_ok = (slotc[NRAW_W - 1] >> 24) != 0;
+  auto conv_store = [&](auto rr, unsigned dst) __attribute__((always_inline)) {
+    constexpr int R = decltype(rr)::value;
+    if (R < NRAW_W - 1 || last_ok) {
+      lds_write64<R * 1024>(dst, cq[0]);
+      lds_write64<R * 1024 + 2 * HALFB>(dst, cq[1]);
+    }
+  };
+
+  // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, image, channel tile;
+  //      B (conv1) = pixel (row 2wv + nt + dy, column j + dx) of the x halo tile; B (conv2) = ring row of t row o + dy - 1,
+  //      column j - 1 + dx (t column index; column -1 / 32 of an edge lane reads a neighbouring row's bytes: those lanes'
+  //      outputs are never stored)
+  const unsigned abase = w_base + hi * 512 + j * 16;
+  const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
+  const unsigned xcen = pl_base + (2 * wv * HWc + j + 1) * 16 + 8 * hi;   // centre pixels (tap (0, 1)), this lane's 4 channels of a k half
+  bf16x8 A[2][NPW][MT], Bq[2][NPX][NT];
+  bf16x8 Ad[MT];
+  auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<DX * WTAP + K * 1024>(A[SET][K / MT][K % MT], aslot);
+  };
+  auto load_b1 = [&](auto setc, auto dyc, auto dxc, auto kc, unsigned bcur) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bcur);
+  };
+  unsigned rowa[4];   // conv2: ring address of t rows o0 - 1 .. o0 + 2 of this wave (k half hi, column j - 1), current chunk
+  auto load_b2 = [&](auto setc, auto dyc, auto dxc, auto kc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    lds_read128<(K / NT) * PLNB + DX * 16>(Bq[SET][K / NT][K % NT], rowa[K % NT + DY]);
+  };
+
+  // 1/S of both images, biases
+  const float sinv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wr1) + WIMG);
+  const float sinv2 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wr2) + WIMG);
+  if (tid < 128) {
+    const float* bp = tid < 64 ? p.bias1 : p.bias2;
+    *(__attribute__((address_space(3))) float*)(bias_lds + tid * 4) = bp ? bp[tid & 63] : 0.0f;
+  }
+
+  f32x16 acc1[MT][NT], acc2[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc1[mt][nt][r] = 0.0f; acc2[mt][nt][r] = 0.0f; }
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // prologue: x chunk 0 -> plane buffer 0, the registers re-load with chunk 1; weight units 0, 1
+  // ------------------------------------------------------------------------------------------------------------------
+  issue_in_begin();
+  set_chunk_rsrc(true);
+  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) { issue_in_piece(rr); });
+#pragma unroll
+  for (int i = 0; i < NW_W; ++i) issue_w_piece(0u, i, true);
+  issue_w_done(true);
+#pragma unroll
+  for (int i = 0; i < NW_W; ++i) issue_w_piece((unsigned)WUNIT, i, true);
+  issue_w_done(true);
+  wait_vmcnt<0>();
+  issue_in_begin();
+  set_chunk_rsrc(true);
+  static_for<0, NRAW_W>([&](auto rr) __attribute__((always_inline)) {
+    constexpr int R = decltype(rr)::value;
+    conv_split(rawr[R]);
+    conv_store(rr, cdst);
+    issue_in_piece(rr);
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  unsigned slot_cur = 0u;   // weight ring slot (byte offset) of the current unit
+  int ug = 0;               // units done by this workgroup
+  int rb = (8 * c0.s + 7) % RSLOT;   // ring slot of t row 8s - 3 (= image row + 10 k), kept per step
+
+  // One unit (kernel row dy of a chunk) = three taps of NG groups of MT * NT MFMAs, fenced by sched_barriers (conv3x3_split.hip).
+  //   KIND 1 (conv1): B from x plane buffer `bcur`; split round 2 dy + dx - 1 of the NEXT x chunk + its re-load ride in group 1 of
+  //   taps 1, 2; the centre-pixel reads / conversions of the residual ride in group 2 of unit 0.
+  //   KIND 2 (conv2): B from the ring; part `e1k` (1 .. 3, or 0 = none) of conv1's epilogue rides in group 1 of taps 1, 2 of
+  //   units 0, 1.
+  u32x2 xr[NPX][NT][2];     // residual: raw f16 x 4 of (plane, nt, k half)
+  float rs[NT][8];          // residual staging of this chunk: x~ of (nt, k half h, e) at [nt][4 h + e]
+  float resid[MT][NT][16];  // x~ at this lane's output pixels, accumulator layout (filled chunk by chunk during conv1)
+  float st[NT][8];          // conv1 epilogue staging: the 16 accumulator values of the part being written
+  unsigned e1addr[NT];      // ring address of this wave's t rows (column j, bytes 8 hi ..) for chunk 0, plane 0, k half 0
+  bool tok[NT];             // t pixel inside the image
+  auto e1_piece = [&](int k, auto ntc, auto hc) __attribute__((always_inline)) {
+    constexpr int nt = decltype(ntc)::value, h = decltype(hc)::value;
+    const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + (16 * k + 8 * h + 4 * hi) * 4);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = fmaxf(st[nt][4 * h + e] * sinv1 + bv[e], 0.0f);   // (1/S is a power of two: exact) + bias, ReLU
+      v[e] = tok[nt] ? t : 0.0f;
+    }
+    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    u32x2 q0, q1;
+    split2_f16(v, q0, q1);
+    const unsigned a = e1addr[nt] + (unsigned)k * CHB;
+    lds_write64<h * KHB>(a, q0);
+    lds_write64<h * KHB + PLNB>(a, q1);
+  };
+  auto e1_stage = [&](int k) __attribute__((always_inline)) {   // st <- acc1 part k = tile k / 2, registers 8 (k % 2) .. + 7
+    switch (k) {
+      case 0:
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) st[nt][r] = acc1[0][nt][r];
+        break;
+      case 1:
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) st[nt][r] = acc1[0][nt][8 + r];
+        break;
+      case 2:
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) st[nt][r] = acc1[1][nt][r];
+        break;
+      default:
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) st[nt][r] = acc1[1][nt][8 + r];
+        break;
+    }
+  };
+
+  auto unit = [&](auto kindc, auto dyc, unsigned bcur, unsigned cnext, bool has_next, bool more_in, bool first_x, int e1k, bool after_e2) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kindc)::value, dy = decltype(dyc)::value;
+    const unsigned slot_nxt = slot_cur == 0u ? (unsigned)((NRING - 1) * WUNIT) : slot_cur - (unsigned)WUNIT;
+    const unsigned aslot = abase + slot_cur;
+    const bool do_w = ug + NRING - 1 < UTOT;
+    static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
+      load_a(std::integral_constant<int, (dy & 1)>(), std::integral_constant<int, 0>(), kc, aslot);
+    });
+    if constexpr (dy == 0) {
+      static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
+        if constexpr (KIND == 1) load_b1(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, bcur);
+        else load_b2(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc);
+      });
+    }
+    static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
+      constexpr int dx = decltype(dxc)::value;
+      constexpr int set = (dy + dx) & 1, nset = set ^ 1;
+      if constexpr (!((C2M_RB_ABL & 32) && dx == 0)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NG>([&](auto gcnt) __attribute__((always_inline)) {
+        constexpr int g = decltype(gcnt)::value;
+        // next tap's operands: (dy, dx + 1): A and B; after the unit's last tap: only B of (dy + 1, 0)
+        static_for<g * LPG, (g + 1) * LPG < NLA + NLB ? (g + 1) * LPG : NLA + NLB>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int K = decltype(kc)::value;
+          if constexpr (dx < 2) {
+            if constexpr (K < NLA) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), kc, aslot);
+            else if constexpr (KIND == 1) load_b1(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>(), bcur);
+            else load_b2(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>());
+          } else if constexpr (dy < 2) {
+            if constexpr (K >= NLA) {
+              if constexpr (KIND == 1) load_b1(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - NLA>(), bcur);
+              else load_b2(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - NLA>());
+            }
+          }
+        });
+        if constexpr (dx == 0) {
+#pragma unroll
+          for (int i = g; i < NW_W; i += NG) issue_w_piece(slot_nxt, i, do_w);
+        }
+        if constexpr (g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const _Float16 s = (_Float16)(1.0f / F16_LO_SCALE);
+            const f16x8 sc = {s, s, s, s, s, s, s, s};
+            Ad[mt] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, A[set][0][mt]) * sc);
+          }
+        }
+        if constexpr (KIND == 1 && dx >= 1 && g == 1) {   // split round R of the next x chunk, then the same slot of the chunk after
+          constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
+          if constexpr (dy == 0 && dx == 1) {
+            if (first_x) wait_vmcnt<0>();   // (chunk 1's raw pieces were issued by the prologue: no unit end since)
+          }
+          conv_split(rawr[R]);
+          conv_store(std::integral_constant<int, R>(), cnext);
+          issue_in_piece(std::integral_constant<int, R>());
+        }
+        if constexpr (KIND == 1 && dy == 0 && g == 2) {
+          // residual: this lane's centre pixels of the chunk (rows 2wv + nt, column j + 1 of the halo tile), both pieces, both k halves
+          if constexpr (dx == 0) {
+            const unsigned xa = xcen + (bcur - bbase);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              if (nt == 0) {
+                lds_read64<0>(xr[0][0][0], xa); lds_read64<HALFB>(xr[0][0][1], xa);
+                lds_read64<2 * HALFB>(xr[1][0][0], xa); lds_read64<3 * HALFB>(xr[1][0][1], xa);
+              } else {
+                lds_read64<HWc * 16>(xr[0][1][0], xa); lds_read64<HWc * 16 + HALFB>(xr[0][1][1], xa);
+                lds_read64<HWc * 16 + 2 * HALFB>(xr[1][1][0], xa); lds_read64<HWc * 16 + 3 * HALFB>(xr[1][1][1], xa);
+              }
+            }
+          } else {   // dx = 1: nt = 0, dx = 2: nt = 1 (the reads completed at the lgkmcnt(0) in front of this tap)
+            constexpr int nt = dx >= 1 ? dx - 1 : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 v0 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[0][nt][h]), f32x4);
+              const f32x4 v1 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[1][nt][h]), f32x4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rs[nt][4 * h + e] = v0[e] + v1[e] * (1.0f / F16_LO_SCALE);   // exact: 22 significant bits
+            }
+          }
+        }
+        if constexpr (KIND == 2 && dy < 2 && dx >= 1 && g == 1) {   // conv1's epilogue, part e1k: (nt, k half) = (dy, dx - 1)
+          if (e1k > 0 && !(p.abl & 64)) e1_piece(e1k, std::integral_constant<int, (dy < 2 ? dy : 0)>(), std::integral_constant<int, (dx >= 1 ? dx - 1 : 0)>());
+        }
+        if constexpr (!(C2M_RB_ABL & 2)) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              // g = 0: w1 . x0,  g = 1: (2^-11 wA) . x1',  g = 2: wA . x0   (smallest terms first; conv3x3_split.hip Flavour<2>)
+              const bf16x8 av = g == 0 ? A[set][1][mt] : g == 1 ? Ad[mt] : A[set][0][mt];
+              const bf16x8 bv = Bq[set][g == 1 ? 1 : 0][nt];
+              if constexpr (KIND == 1)
+                acc1[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc1[mt][nt], 0, 0, 0);
+              else
+                acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc2[mt][nt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (dx == 0) issue_w_done(do_w);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the weights of unit u + 1 (issued in unit u - 1) must have landed; still in flight may be whatever was issued after them:
+    // the two raw loads of unit u - 1 (if it was a conv1 unit), this unit's NW_W pieces and its two raw loads (conv1).  After the
+    // output stores of a step the count is the strict one: the stores drain here (as in the split kernel).
+    if constexpr (!(C2M_RB_ABL & 8)) {
+      if constexpr (KIND == 1) {
+        if (dy == 0 && after_e2) wait_vmcnt<NW_W + 2>();
+        else wait_vmcnt<NW_W + 4>();
+      } else {
+        if (dy == 0 && after_e2) wait_vmcnt<NW_W + 2>();   // (here: the first conv2 unit, behind conv1's last)
+        else wait_vmcnt<NW_W>();
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    slot_cur = slot_cur == (unsigned)((NRING - 1) * WUNIT) ? 0u : slot_cur + (unsigned)WUNIT;
+    ++ug;
+  };
+
+  for (int stp = 0, xi = 0; stp < nst; ++stp) {
+    // ---- per-step geometry (epilogue cursor)
+    const int b = epi_cur.b, s = epi_cur.s, x0 = OW * epi_cur.strip;   // first output column of the strip
+    cur_next(epi_cur);
+    const bool store_ok = !(prime && stp == 0);
+    // ring slots: t row 8s - 3 + i <-> slot (rb + i) % 10
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int sl = rb + 2 * wv + i;
+      sl = sl >= RSLOT ? sl - RSLOT : sl;
+      sl = sl >= RSLOT ? sl - RSLOT : sl;
+      rowa[i] = ring + hi * KHB + sl * ROWB + (j - 1) * 16;      // (chunk 0; advanced by CHB per conv2 chunk)
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int sl = rb + 2 + 2 * wv + nt;                             // t row 8s - 1 + 2wv + nt
+      sl = sl >= RSLOT ? sl - RSLOT : sl;
+      sl = sl >= RSLOT ? sl - RSLOT : sl;
+      e1addr[nt] = ring + sl * ROWB + j * 16 + 8 * hi;
+      const int ty = 8 * s - 1 + 2 * wv + nt, tx = x0 - 1 + j;
+      tok[nt] = (unsigned)ty < (unsigned)p.H && (unsigned)tx < (unsigned)p.W;
+    }
+    rb = rb + 8 >= RSLOT ? rb + 8 - RSLOT : rb + 8;
+
+    // ---- conv1: four x chunks
+    for (int c = 0; c < 4; ++c, ++xi) {
+      const bool has_next = xi + 1 < G, more_in = xi + 2 < G;
+      const unsigned pb = (unsigned)(xi & 1) * PLB;
+      const unsigned bcur = bbase + pb, cnext = cdst + (PLB - pb);
+      if (more_in) issue_in_begin();
+      set_chunk_rsrc(more_in);
+      (void)has_next;
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), bcur, cnext, has_next, more_in, xi == 0, 0, c == 0 && stp > 0);
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), bcur, cnext, has_next, more_in, false, 0, false);
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 2>(), bcur, cnext, has_next, more_in, false, 0, false);
+      // residual: x~ of this chunk's 16 channels, kept until the output epilogue (accumulator layout)
+      switch (c) {
+        case 0:
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) resid[0][nt][r] = rs[nt][r];
+          break;
+        case 1:
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) resid[0][nt][8 + r] = rs[nt][r];
+          break;
+        case 2:
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) resid[1][nt][r] = rs[nt][r];
+          break;
+        default:
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) resid[1][nt][8 + r] = rs[nt][r];
+          break;
+      }
+    }
+
+    // ---- conv1's epilogue, part 0 (channels 0 .. 15 of t: what conv2's first chunk multiplies), then publish it
+    if (!(p.abl & 64)) {
+    e1_stage(0);
+    e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+    e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- conv2: four ring chunks; parts 1 .. 3 of conv1's epilogue ride in chunks 0 .. 2
+    for (int c2 = 0; c2 < 4; ++c2) {
+      const int e1k = c2 < 3 ? c2 + 1 : 0;
+      if (e1k > 0 && !(p.abl & 64)) e1_stage(e1k);
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 0>(), 0u, 0u, false, false, false, e1k, c2 == 0);
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 1>(), 0u, 0u, false, false, false, e1k, false);
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 2>(), 0u, 0u, false, false, false, 0, false);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rowa[i] += (unsigned)CHB;
+    }
+
+    // ---- output: rows 8s - 2 + 2wv + nt, columns x0 - 1 + j (j = 1 .. 30)
+    if (!(p.abl & 16))
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int y = 8 * s - 2 + 2 * wv + nt, x = x0 - 1 + j;
+      const bool pok = store_ok && j >= 1 && j <= OW && (unsigned)y < (unsigned)p.H && x < p.W;
+      const size_t opix = (size_t)b * p.out_img_pitch + (size_t)(pok ? y : 0) * p.out_row_pitch + (size_t)(pok ? x : 0) * p.out_pix_pitch;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + 256 + (mt * 32 + 8 * qd + 4 * hi) * 4);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (acc2[mt][nt][4 * qd + e] * sinv2 + bv[e]) + resid[mt][nt][4 * qd + e];
+          if (pok && !(p.abl & 1)) {
+            const size_t o = opix + 4 * hi + mt * 32 + 8 * qd;
+            if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + o);
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+          }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[mt][nt][r] = 0.0f; acc2[mt][nt][r] = 0.0f; }
+  }
+  if (p.range_flag != nullptr && !(amax < 65520.0f)) *p.range_flag = 1;   // (rare, idempotent store; inf counts)
+}
+
+}  // namespace rb
+}  // namespace conv
+}  // namespace c2m
+
+// =====================================================================================================================
+// C-ABI
+// =====================================================================================================================
+using namespace c2m;
+
+extern "C" int c2m_resblock3x3_supported(int C, int H, int W) {
+  return C == 64 && H >= 1 && W >= 1;
+}
+
+extern "C" int c2m_resblock3x3_nhwc_f32(c2m_stream_t stream, const c2m_resblock3x3_desc* d) {
+  if (!d || !d->x || !d->out || !d->wr1 || !d->wr2) return C2M_ERR_INVALID_ARG;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return C2M_ERR_INVALID_ARG;
+  if (d->C != 64) return C2M_ERR_UNSUPPORTED;
+  // 16-byte pieces; 32-bit byte offsets inside one sample (buffer addressing), bit 31 marks "outside"
+  if (d->x_pix_pitch % 4 || d->x_row_pitch % 4 || d->x_img_pitch % 4 || ((uintptr_t)d->x & 15)) return C2M_ERR_UNSUPPORTED;
+  if (d->out_pix_pitch % 4 || d->out_row_pitch % 4 || d->out_img_pitch % 4 || ((uintptr_t)d->out & 15) || ((uintptr_t)d->res2 & 15)) return C2M_ERR_UNSUPPORTED;
+  if (d->x_pix_pitch < 64 || d->x_row_pitch < 0 || d->out_pix_pitch < 64 || d->out_row_pitch < 0) return C2M_ERR_UNSUPPORTED;
+  const long long ext = ((long long)(d->H - 1) * d->x_row_pitch + (long long)(d->W - 1) * d->x_pix_pitch + 64) * 4;
+  if (ext >= 0x7fffffffLL) return C2M_ERR_UNSUPPORTED;
+  conv::rb::Params p;
+  p.x.ptr = d->x; p.x.C = 64; p.x.pix_pitch = d->x_pix_pitch; p.x.row_pitch = d->x_row_pitch; p.x.img_pitch = d->x_img_pitch;
+  p.out = d->out; p.out_pix_pitch = d->out_pix_pitch; p.out_row_pitch = d->out_row_pitch; p.out_img_pitch = d->out_img_pitch;
+  p.res2 = d->res2; p.wr1 = d->wr1; p.wr2 = d->wr2; p.bias1 = d->bias1; p.bias2 = d->bias2;
+  p.B = d->B; p.H = d->H; p.W = d->W;
+  p.nstrips = ceil_div(d->W, conv::rb::OW);
+  p.nsteps = ceil_div(d->H + 2, 8);
+  const long long total = (long long)d->B * p.nstrips * p.nsteps;
+  if (total > 0x3fffffffLL) return C2M_ERR_UNSUPPORTED;
+  p.total = (int)total;
+  p.range_flag = d->range_flag;
+  static const int env_abl = [] { const char* e = getenv("C2M_RB_ABLR"); const int v = e ? atoi(e) : 0; if (v) fprintf(stderr, "c2m: C2M_RB_ABLR=%d -- the fused residual-block kernel runs a timing-only ablation, its results are wrong\n", v); return v; }();
+  p.abl = env_abl;
+  hipStream_t st = as_stream(stream);
+  static int ncu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return C2M_ERR_NO_DEVICE;
+  if (ncu[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu[dev] = n;
+  }
+  static const int env_wgs = [] { const char* e = getenv("C2M_RB_WGS"); return e ? atoi(e) : 0; }();
+  const int wgs = (int)std::min<long long>(env_wgs > 0 ? env_wgs : ncu[dev], total);
+  static unsigned long long done = 0;
+  int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv::rb::resblock_kernel), conv::rb::LDS_BYTES, done);
+  if (rc != C2M_OK) return rc;
+  ProfileScope prof(C2M_KERNEL_CONV3X3_SPLIT, st);
+  hipLaunchKernelGGL(conv::rb::resblock_kernel, dim3(wgs), dim3(256), conv::rb::LDS_BYTES, st, p);
+  return check_launch();
+}

@@ -99,7 +99,8 @@ def _train_body(body, f, skip=None):
 
 
 def _fused_body(body, f, skip=None):
-    """16 x (x + conv2(relu(conv1(x)))) (arch_util.py:128-136), two launches per block; `skip` (the stage input,
+    """16 x (x + conv2(relu(conv1(x)))) (arch_util.py:128-136), one launch per block on large maps (ops.resblock3x3), two
+    otherwise; `skip` (the stage input,
     ref_restoration_arch.py:153,166,179 `h = body(h) + x`) rides on the last block's epilogue.  fast=True: decoder
     convolutions may take the Winograd F(4,3) kernel (ops.conv3x3) where the map is a whole number of 64-pixel tiles wide."""
     n = len(body)
@@ -113,6 +114,13 @@ def _fused_body(body, f, skip=None):
             t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU, fast=True, out_dtype=bf)
             f = _ops.conv3x3(t, blk.conv2.weight, blk.conv2.bias, res1=f, res2=skip if k == n - 1 else None, fast=True,
                              out_dtype=None if k == n - 1 else bf)
+        return f
+    if _ops.resblock3x3_wanted(f) and all(_ops.resblock3x3_ok(f, blk.conv1.weight, blk.conv2.weight) for blk in body):
+        # one launch per block (csrc/conv3x3_resblock.hip): the intermediate tensor stays in LDS, the identity comes from the f16
+        # pieces of x the kernel holds anyway -- 2 tensor passes per block instead of 5
+        for k, blk in enumerate(body):
+            f = _ops.resblock3x3(f, blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias,
+                                 res2=skip if k == n - 1 else None)
         return f
     for k, blk in enumerate(body):
         t = _ops.conv3x3(f, blk.conv1.weight, blk.conv1.bias, act=_ops.ACT_RELU, fast=True)

@@ -43,7 +43,7 @@ typedef enum c2m_status {
   C2M_ERR_NO_DEVICE = 5      /* no gfx950 device visible to the HIP runtime */
 } c2m_status;
 
-int c2m_abi_version(void);                 /* bumped on any signature change; currently 2 */
+int c2m_abi_version(void);                 /* bumped on any signature change; currently 3 (round 6: c2m_resblock3x3_*) */
 const char* c2m_status_string(int status); /* static string, never NULL */
 const char* c2m_last_hip_error(void);      /* hipGetErrorString of the last failing HIP call on this thread */
 int c2m_device_arch(char* buf, int buflen);/* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
@@ -385,6 +385,40 @@ int c2m_conv3x3_rgb64_f32(c2m_stream_t stream, const float* image, int B, int H,
 /* max_idx [B][hq][wq] int64 -> flow [B][hq][wq][2] fp32 (x, y) = (idx % wq - x, idx / wq - y): index_to_flow of
  * corres_generation_arch.py:29-46 for the whole batch, without the zero padding (the consumer bounds-checks). */
 int c2m_index_to_flow_f32(c2m_stream_t stream, const int64_t* max_idx, int B, int hq, int wq, float* flow);
+
+/*
+ * A whole ResidualBlockNoBN of the decoder bodies in ONE launch (csrc/conv3x3_resblock.hip):
+ *
+ *     out = x + conv2( relu( conv1(x) + bias1 ) ) + bias2  [+ res2]
+ *
+ * replaces mmsr/models/archs/arch_util.py:128-136 (`identity + conv2(relu(conv1(x)))`, res_scale 1) -- 96 of them behind
+ * ref_restoration_arch.py:91-98,115-122,138-145,158,171,184 -- and, through res2, the stage skip `body(h) + x` of
+ * ref_restoration_arch.py:153,166,179 on a body's last block.  C = 64 channels in and out, fp32 channels-last tensors with
+ * explicit pitches (floats, multiples of 4; one sample addressed with 32-bit byte offsets), any H, W.  Arithmetic: the f16 x 2
+ * flavour of c2m_conv3x3_nhwc_f32 (C2M_CONV_SPLIT_F16X2) for both convolutions -- wr1 / wr2 are the images
+ * c2m_conv3x3_relayout_split_f32(pieces = 2) makes for conv1 / conv2 (the SAME cached images the two-launch path uses).  The
+ * intermediate tensor never leaves the CU (a ring of f16 x 2 planes in LDS, sliding down 30-column strips) and the identity
+ * is rebuilt from the two f16 pieces of x the kernel holds anyway (x~ = x0 + 2^-11 x1', |x - x~| <= 2^-22 |x|): results agree
+ * with the two-launch path to that rounding, not bit for bit.  Domain |x|, |relu(conv1)| < 65520, reported through
+ * range_flag like C2M_CONV_SPLIT_F16X2.  C2M_ERR_UNSUPPORTED for C != 64 or extents beyond 2^31 bytes per sample.
+ */
+typedef struct c2m_resblock3x3_desc {
+  int B, H, W, C;           /* C = 64 */
+  const float* x;           /* input = identity: pixel (0,0), channel 0, sample 0 */
+  int x_pix_pitch, x_row_pitch;
+  long long x_img_pitch;
+  float* out;               /* may not alias x (a step reads halo rows other workgroups' steps write) */
+  int out_pix_pitch, out_row_pitch;
+  long long out_img_pitch;
+  const float* res2;        /* NULL, or a tensor with out's geometry added to the result */
+  const void* wr1;          /* conv1 / conv2 weights: c2m_conv3x3_relayout_split_f32(Cin 64, Cout 64, pieces 2) */
+  const void* wr2;
+  const float* bias1;       /* [64] or NULL */
+  const float* bias2;
+  int* range_flag;          /* as c2m_conv3x3_desc.range_flag, or NULL */
+} c2m_resblock3x3_desc;
+int c2m_resblock3x3_supported(int C, int H, int W);   /* 1 if c2m_resblock3x3_nhwc_f32 takes this shape */
+int c2m_resblock3x3_nhwc_f32(c2m_stream_t stream, const c2m_resblock3x3_desc* d);
 
 #ifdef __cplusplus
 }

@@ -166,6 +166,9 @@ PY
                   rm -rf $O/pmcd_$i $O/pmcc_$i
                 done
                 cd $R ;;
+    diag_rb)    timeout 600 python scripts/diag_resblock.py ${RB_ARGS:-check time} > $O/diag_resblock.log 2>&1; echo "rc=$?" >> $O/diag_resblock.log ;;
+    abl_rbk)    (for m in "" ${RBK_MASKS:-8 16 32 40 56 64 120 2} ""; do echo "=== ${m:-in-tree} (C2M_RB_ABL: 1 no stores, 2 no MFMAs, 4 no x loads, 8 no unit-end waits/barriers, 16 no output epilogue, 32 no operand wait before a unit's first tap, 64 no conv1 epilogue)"; C2M_LIB=${m:+$R/build_exp/libc2m_rb$m.so} timeout 200 python scripts/diag_resblock.py time 2>&1 | grep "^{"; done) > $O/abl_resblock_kernel.log 2>&1 ;;
+    abl_rbr)    (for m in 0 ${RBR_MASKS:-1 16 64 80} 0; do echo "=== C2M_RB_ABLR=$m (runtime, no dead-code elimination: 1 no output stores, 16 no output epilogue, 64 no conv1 epilogue)"; C2M_RB_ABLR=$m timeout 200 python scripts/diag_resblock.py time 2>&1 | grep "^{"; done) > $O/abl_resblock_runtime.log 2>&1 ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac

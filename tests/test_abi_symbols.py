@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(c2m_amd.LIB_PATH)
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.c2m_abi_version() == 2
+    assert lib.c2m_abi_version() == 3
     lib.c2m_status_string.restype = ctypes.c_char_p
     assert lib.c2m_status_string(0) == b"ok" and b"workspace" in lib.c2m_status_string(3)
 
