@@ -841,10 +841,13 @@ def conv3x3(srcs, weight, bias=None, act=ACT_NONE, slope=0.1, res1=None, res2=No
     return out
 
 
-# C2M_RESBLOCK: "auto" (default) -- the fused inference bodies run a whole ResidualBlockNoBN (arch_util.py:80-136) as ONE launch
-# (csrc/conv3x3_resblock.hip) where the f16 x 2 flavour is active and the map has at least C2M_RESBLOCK_MINPIX pixels; "0" -- two
-# launches per block (conv3x3 twice) everywhere; "1" -- wherever the kernel supports the shape.
-_RESBLOCK = _os.environ.get("C2M_RESBLOCK", "auto")
+# C2M_RESBLOCK: "0" (default) -- a ResidualBlockNoBN (arch_util.py:80-136) is two conv3x3 launches; "1" -- the fused inference
+# bodies run it as ONE launch (csrc/experimental/conv3x3_resblock.hip: the intermediate tensor stays in LDS) on maps of at least
+# C2M_RESBLOCK_MINPIX pixels, IF the library was built with `make EXPERIMENTAL=1`.  Round 6 built and measured it:
+# right on its first run on hardware, equal to the two-launch path to 1 ulp -- and 6 - 7 % SLOWER at 640^2 / 320^2, 25 % at 160^2
+# (on this chip a wave's vector-ALU instructions are paid for in matrix-pipe time whether or not another wave
+# runs beside it, and the fused form needs 11 % more MFMAs plus more vector work per MFMA).  A recorded no-go, kept for its numbers.
+_RESBLOCK = _os.environ.get("C2M_RESBLOCK", "0")
 _RESBLOCK_MINPIX = int(_os.environ.get("C2M_RESBLOCK_MINPIX", str(300 * 300)))
 
 
@@ -857,15 +860,16 @@ def resblock3x3_ok(x, w1, w2, res2=None):
 
 def resblock3x3_wanted(x):
     """The policy of the fused bodies (ref_restoration_arch._fused_body): f16 x 2 active for this thread's auto calls, map large enough."""
-    if _RESBLOCK == "0" or _SPLIT == "0" or not _f16x2_auto():
+    if _RESBLOCK != "1" or _SPLIT == "0" or not _f16x2_auto():
         return False
-    return _RESBLOCK == "1" or x.shape[2] * x.shape[3] >= _RESBLOCK_MINPIX
+    return x.shape[2] * x.shape[3] >= _RESBLOCK_MINPIX and bool(_lib.lib().c2m_resblock3x3_supported(64, x.shape[2], x.shape[3]))
 
 
 def resblock3x3(x, w1, b1, w2, b2, res2=None, out=None):
     """out = x + conv2(relu(conv1(x) + b1)) + b2 (+ res2): a ResidualBlockNoBN (arch_util.py:128-136, res_scale 1) in ONE launch
     on the f16 x 2 arithmetic (c2m_resblock3x3_nhwc_f32: the intermediate tensor stays in LDS, x is read once, the identity is
     rebuilt from x's two f16 pieces -- equal to two conv3x3(algo="split16") launches up to that rounding, |d| <= 2^-22 |x|).
+    Needs a library built with `make EXPERIMENTAL=1` (C2MError "unsupported" otherwise): a measured no-go, see _RESBLOCK above.
     x: channels_last [B,64,H,W] fp32; domain as algo="split16" (range flag of the enclosing guard / the device)."""
     if not resblock3x3_ok(x, w1, w2, res2):
         raise _lib.C2MError("resblock3x3: channels_last float32 GPU tensor [B,64,H,W], weights [64,64,3,3]")

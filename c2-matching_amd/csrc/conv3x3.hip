@@ -1484,6 +1484,14 @@ inline long long relayout_elems(int Cin, int Cout) {
 }
 }  // namespace
 
+#ifndef C2M_EXPERIMENTAL
+// csrc/experimental/conv3x3_resblock.hip (a whole ResidualBlockNoBN in one launch) is a measured no-go: correct,
+// 6 - 7 % slower than two launches of the split kernel.  It is built by `make EXPERIMENTAL=1` only; the product library answers
+// "unsupported" and callers (c2m_amd.ops.resblock3x3_wanted) stay on the two-launch path.
+extern "C" int c2m_resblock3x3_supported(int, int, int) { return 0; }
+extern "C" int c2m_resblock3x3_nhwc_f32(c2m_stream_t, const c2m_resblock3x3_desc*) { return C2M_ERR_UNSUPPORTED; }
+#endif
+
 extern "C" size_t c2m_conv3x3_relayout_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0 || Cin % conv::KCH != 0) return 0;
   return (size_t)(relayout_elems(Cin, Cout) + 64) * sizeof(float);

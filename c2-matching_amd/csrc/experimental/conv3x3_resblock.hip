@@ -258,11 +258,13 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
   // ---- operands: A = lane (cout row j, k half hi) of the ring slot's tap dx, image, channel tile;
   //      B (conv1) = pixel (row 2wv + nt + dy, column j + dx) of the x halo tile; B (conv2) = ring row of t row o + dy - 1,
   //      column j - 1 + dx (t column index; column -1 / 32 of an edge lane reads a neighbouring row's bytes: those lanes'
-  //      outputs are never stored)
+  //      outputs are never stored).  THREE operand sets: tap dx of a unit multiplies set dx while the next tap's operands land
+  //      in set (dx + 1) % 3 -- a unit's LAST tap fetches the NEXT unit's first-tap operands (behind the unit's barrier, which
+  //      sits in front of that tap), so no unit starts by waiting for LDS.
   const unsigned abase = w_base + hi * 512 + j * 16;
   const unsigned bbase = pl_base + hi * HALFB + (2 * wv * HWc + j) * 16;
   const unsigned xcen = pl_base + (2 * wv * HWc + j + 1) * 16 + 8 * hi;   // centre pixels (tap (0, 1)), this lane's 4 channels of a k half
-  bf16x8 A[2][NPW][MT], Bq[2][NPX][NT];
+  bf16x8 A[3][NPW][MT], Bq[3][NPX][NT];
   bf16x8 Ad[MT];
   auto load_a = [&](auto setc, auto dxc, auto kc, unsigned aslot) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
@@ -273,9 +275,9 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
     lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bcur);
   };
   unsigned rowa[4];   // conv2: ring address of t rows o0 - 1 .. o0 + 2 of this wave (k half hi, column j - 1), current chunk
-  auto load_b2 = [&](auto setc, auto dyc, auto dxc, auto kc) __attribute__((always_inline)) {
+  auto load_b2 = [&](auto setc, auto dyc, auto dxc, auto kc, unsigned choff) __attribute__((always_inline)) {
     constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
-    lds_read128<(K / NT) * PLNB + DX * 16>(Bq[SET][K / NT][K % NT], rowa[K % NT + DY]);
+    lds_read128<(K / NT) * PLNB + DX * 16>(Bq[SET][K / NT][K % NT], rowa[K % NT + DY] + choff);
   };
 
   // 1/S of both images, biases
@@ -318,6 +320,7 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  bool pending_prev_chunk = false;
   unsigned slot_cur = 0u;   // weight ring slot (byte offset) of the current unit
   int ug = 0;               // units done by this workgroup
   int rb = (8 * c0.s + 7) % RSLOT;   // ring slot of t row 8s - 3 (= image row + 10 k), kept per step
@@ -378,38 +381,94 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
     }
   };
 
-  auto unit = [&](auto kindc, auto dyc, unsigned bcur, unsigned cnext, bool has_next, bool more_in, bool first_x, int e1k, bool after_e2) __attribute__((always_inline)) {
+  // deferred output: the finished values of a step stay in `resid` and are stored 4 x 16 bytes at a time at the end of the next
+  // step's conv1 chunks, right before that chunk's residual overwrites them -- no store sits exposed between two steps
+  float* ob_prev[NT] = {p.out, p.out};
+  bool pok_prev[NT] = {false, false};
+  bool pending = false;
+  auto store_part = [&](auto mtc, auto halfc) __attribute__((always_inline)) {   // channels mt * 32 + 16 half .. + 15 of both rows
+    constexpr int mt = decltype(mtc)::value, hf = decltype(halfc)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int qd = 2 * hf + q;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = resid[mt][nt][4 * qd + e];
+        if (pok_prev[nt] && !(p.abl & 1)) *reinterpret_cast<f32x4*>(ob_prev[nt] + mt * 32 + 8 * qd) = v;
+      }
+  };
+
+  // One unit (kernel row dy of a chunk) = three taps of NG groups of MT * NT MFMAs, fenced by sched_barriers (conv3x3_split.hip).
+  // The unit's vector-memory wait and barrier sit IN FRONT OF ITS LAST TAP: by then every wave has this unit's operands in
+  // registers (the ring slot is free), the weights of unit u + 1 have landed (issued in unit u - 1) and every LDS write issued
+  // before (split rounds, conv1's epilogue pieces) is published -- so the last tap's groups fetch the next unit's first-tap
+  // operands and no unit starts by waiting for LDS.
+  //   KIND 1 (conv1): B from x plane buffer `bcur`; split round 2 dy + dx of the NEXT x chunk + its re-load ride in taps 0 (group 2,
+  //   behind the tap's last weight piece) and 1 (group 1); the residual's centre-pixel reads ride in (1, 2), its conversions in (2, 2).
+  //   KIND 2 (conv2): B from the ring (+ choff = chunk offset); part `e1k` (1 .. 3, or 0 = none) of conv1's epilogue rides in group 1
+  //   of taps 1, 2 of units 0, 1.
+  // nextb: where the next unit's first-tap B operands come from at dy == 2 (0: not available yet -- the next unit loads them itself;
+  // 1: x plane buffer at `bnext`; 2: ring chunk at choff + CHB); vm_extra: vector-memory instructions issued between the previous
+  // unit's last weight piece and this unit beyond the usual ones (deferred stores).
+  auto unit = [&](auto kindc, auto dyc, unsigned bcur, unsigned cnext, unsigned choff, bool first_x, int e1k, int nextb, unsigned bnext,
+                  bool have_a, bool have_b, int vm_extra) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kindc)::value, dy = decltype(dyc)::value;
-    const unsigned slot_nxt = slot_cur == 0u ? (unsigned)((NRING - 1) * WUNIT) : slot_cur - (unsigned)WUNIT;
-    const unsigned aslot = abase + slot_cur;
+    const unsigned slot_nxt = slot_cur == 0u ? (unsigned)((NRING - 1) * WUNIT) : slot_cur - (unsigned)WUNIT;        // unit u + 2 lands here
+    const unsigned slot_u1 = slot_cur == (unsigned)((NRING - 1) * WUNIT) ? 0u : slot_cur + (unsigned)WUNIT;        // unit u + 1 lives here
+    const unsigned aslot = abase + slot_cur, aslot_n = abase + slot_u1;
     const bool do_w = ug + NRING - 1 < UTOT;
-    static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
-      load_a(std::integral_constant<int, (dy & 1)>(), std::integral_constant<int, 0>(), kc, aslot);
-    });
-    if constexpr (dy == 0) {
+    if (!have_a) {
+      static_for<0, NLA>([&](auto kc) __attribute__((always_inline)) {
+        load_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, aslot);
+      });
+    }
+    if (!have_b) {
       static_for<0, NLB>([&](auto kc) __attribute__((always_inline)) {
-        if constexpr (KIND == 1) load_b1(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, bcur);
-        else load_b2(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc);
+        if constexpr (KIND == 1) load_b1(std::integral_constant<int, 0>(), dyc, std::integral_constant<int, 0>(), kc, bcur);
+        else load_b2(std::integral_constant<int, 0>(), dyc, std::integral_constant<int, 0>(), kc, choff);
       });
     }
     static_for<0, 3>([&](auto dxc) __attribute__((always_inline)) {
       constexpr int dx = decltype(dxc)::value;
-      constexpr int set = (dy + dx) & 1, nset = set ^ 1;
-      if constexpr (!((C2M_RB_ABL & 32) && dx == 0)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int set = dx, nset = (dx + 1) % 3;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (dx == 2 && !(C2M_RB_ABL & 8)) {
+        // in flight may stay: whatever was issued after the last weight piece of unit u - 1 -- its two raw loads (conv1), the
+        // deferred stores of a chunk end, this unit's three pieces and its two raw loads (conv1)
+        if constexpr (KIND == 1) {
+          if (vm_extra == 0) wait_vmcnt<NW_W + 4>();
+          else if (vm_extra == 4) wait_vmcnt<NW_W + 8>();
+          else wait_vmcnt<NW_W + 2>();          // (-2: the previous unit was a conv2 unit)
+        } else {
+          if (vm_extra == 0) wait_vmcnt<NW_W>();
+          else if (vm_extra == 2) wait_vmcnt<NW_W + 2>();   // (the first conv2 unit: conv1's last two raw loads ...
+          else wait_vmcnt<NW_W + 6>();                      //  ... + four deferred stores)
+        }
+        __builtin_amdgcn_s_barrier();
+      }
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NG>([&](auto gcnt) __attribute__((always_inline)) {
         constexpr int g = decltype(gcnt)::value;
-        // next tap's operands: (dy, dx + 1): A and B; after the unit's last tap: only B of (dy + 1, 0)
+        // next tap's operands -> set nset: (dy, dx + 1): A and B; at the unit's last tap: A of the next unit's first tap, B of (dy + 1, 0)
+        // (dy == 2: of the next chunk's (0, 0), if it exists already)
         static_for<g * LPG, (g + 1) * LPG < NLA + NLB ? (g + 1) * LPG : NLA + NLB>([&](auto kc) __attribute__((always_inline)) {
           constexpr int K = decltype(kc)::value;
+          constexpr int KB = K >= NLA ? K - NLA : 0;
           if constexpr (dx < 2) {
             if constexpr (K < NLA) load_a(std::integral_constant<int, nset>(), std::integral_constant<int, dx + 1>(), kc, aslot);
-            else if constexpr (KIND == 1) load_b1(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>(), bcur);
-            else load_b2(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, K - NLA>());
-          } else if constexpr (dy < 2) {
-            if constexpr (K >= NLA) {
-              if constexpr (KIND == 1) load_b1(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - NLA>(), bcur);
-              else load_b2(std::integral_constant<int, nset>(), std::integral_constant<int, dy + 1>(), std::integral_constant<int, 0>(), std::integral_constant<int, K - NLA>());
+            else if constexpr (KIND == 1) load_b1(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, KB>(), bcur);
+            else load_b2(std::integral_constant<int, nset>(), dyc, std::integral_constant<int, dx + 1>(), std::integral_constant<int, KB>(), choff);
+          } else {
+            if constexpr (K < NLA) {
+              load_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), kc, aslot_n);
+            } else if constexpr (dy < 2) {
+              if constexpr (KIND == 1) load_b1(std::integral_constant<int, 0>(), std::integral_constant<int, (dy < 2 ? dy + 1 : 0)>(), std::integral_constant<int, 0>(), std::integral_constant<int, KB>(), bcur);
+              else load_b2(std::integral_constant<int, 0>(), std::integral_constant<int, (dy < 2 ? dy + 1 : 0)>(), std::integral_constant<int, 0>(), std::integral_constant<int, KB>(), choff);
+            } else {
+              if (nextb == 1) load_b1(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, KB>(), bnext);
+              else if (nextb == 2) load_b2(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), std::integral_constant<int, KB>(), choff + (unsigned)CHB);
             }
           }
         });
@@ -420,43 +479,36 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
         if constexpr (g == 0) {   // wB = 2^-11 wA of this tap (used by group 1)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const _Float16 s = (_Float16)(1.0f / F16_LO_SCALE);
-            const f16x8 sc = {s, s, s, s, s, s, s, s};
+            const _Float16 sh = (_Float16)(1.0f / F16_LO_SCALE);
+            const f16x8 sc = {sh, sh, sh, sh, sh, sh, sh, sh};
             Ad[mt] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(f16x8, A[set][0][mt]) * sc);
           }
         }
-        if constexpr (KIND == 1 && dx >= 1 && g == 1) {   // split round R of the next x chunk, then the same slot of the chunk after
-          constexpr int R = dx >= 1 ? 2 * dy + dx - 1 : 0;
-          if constexpr (dy == 0 && dx == 1) {
-            if (first_x) wait_vmcnt<0>();   // (chunk 1's raw pieces were issued by the prologue: no unit end since)
+        if constexpr (KIND == 1 && ((dx == 0 && g == 2) || (dx == 1 && g == 1))) {   // split round R of the next x chunk, then the same slot of the chunk after
+          constexpr int R = dx < 2 ? 2 * dy + dx : 0;
+          if constexpr (dy == 0 && dx == 0) {
+            if (first_x) wait_vmcnt<0>();   // (chunk 1's raw pieces were issued by the prologue: no unit-end wait since)
           }
           conv_split(rawr[R]);
           conv_store(std::integral_constant<int, R>(), cnext);
           issue_in_piece(std::integral_constant<int, R>());
         }
-        if constexpr (KIND == 1 && dy == 0 && g == 2) {
+        if constexpr (KIND == 1 && dy == 1 && dx == 2 && g == 2) {
           // residual: this lane's centre pixels of the chunk (rows 2wv + nt, column j + 1 of the halo tile), both pieces, both k halves
-          if constexpr (dx == 0) {
-            const unsigned xa = xcen + (bcur - bbase);
+          const unsigned xa = xcen + (bcur - bbase);
+          lds_read64<0>(xr[0][0][0], xa); lds_read64<HALFB>(xr[0][0][1], xa);
+          lds_read64<2 * HALFB>(xr[1][0][0], xa); lds_read64<3 * HALFB>(xr[1][0][1], xa);
+          lds_read64<HWc * 16>(xr[0][1][0], xa); lds_read64<HWc * 16 + HALFB>(xr[0][1][1], xa);
+          lds_read64<HWc * 16 + 2 * HALFB>(xr[1][1][0], xa); lds_read64<HWc * 16 + 3 * HALFB>(xr[1][1][1], xa);
+        }
+        if constexpr (KIND == 1 && dy == 2 && dx == 2 && g >= 1) {   // (the reads completed at an lgkmcnt(0) since)
+          constexpr int nt = g >= 1 ? g - 1 : 0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              if (nt == 0) {
-                lds_read64<0>(xr[0][0][0], xa); lds_read64<HALFB>(xr[0][0][1], xa);
-                lds_read64<2 * HALFB>(xr[1][0][0], xa); lds_read64<3 * HALFB>(xr[1][0][1], xa);
-              } else {
-                lds_read64<HWc * 16>(xr[0][1][0], xa); lds_read64<HWc * 16 + HALFB>(xr[0][1][1], xa);
-                lds_read64<HWc * 16 + 2 * HALFB>(xr[1][1][0], xa); lds_read64<HWc * 16 + 3 * HALFB>(xr[1][1][1], xa);
-              }
-            }
-          } else {   // dx = 1: nt = 0, dx = 2: nt = 1 (the reads completed at the lgkmcnt(0) in front of this tap)
-            constexpr int nt = dx >= 1 ? dx - 1 : 0;
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 v0 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[0][nt][h]), f32x4);
+            const f32x4 v1 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[1][nt][h]), f32x4);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const f32x4 v0 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[0][nt][h]), f32x4);
-              const f32x4 v1 = __builtin_convertvector(__builtin_bit_cast(f16x4, xr[1][nt][h]), f32x4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rs[nt][4 * h + e] = v0[e] + v1[e] * (1.0f / F16_LO_SCALE);   // exact: 22 significant bits
-            }
+            for (int e = 0; e < 4; ++e) rs[nt][4 * h + e] = v0[e] + v1[e] * (1.0f / F16_LO_SCALE);   // exact: 22 significant bits
           }
         }
         if constexpr (KIND == 2 && dy < 2 && dx >= 1 && g == 1) {   // conv1's epilogue, part e1k: (nt, k half) = (dy, dx - 1)
@@ -480,24 +532,11 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
       });
       if constexpr (dx == 0) issue_w_done(do_w);
     });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // the weights of unit u + 1 (issued in unit u - 1) must have landed; still in flight may be whatever was issued after them:
-    // the two raw loads of unit u - 1 (if it was a conv1 unit), this unit's NW_W pieces and its two raw loads (conv1).  After the
-    // output stores of a step the count is the strict one: the stores drain here (as in the split kernel).
-    if constexpr (!(C2M_RB_ABL & 8)) {
-      if constexpr (KIND == 1) {
-        if (dy == 0 && after_e2) wait_vmcnt<NW_W + 2>();
-        else wait_vmcnt<NW_W + 4>();
-      } else {
-        if (dy == 0 && after_e2) wait_vmcnt<NW_W + 2>();   // (here: the first conv2 unit, behind conv1's last)
-        else wait_vmcnt<NW_W>();
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    slot_cur = slot_cur == (unsigned)((NRING - 1) * WUNIT) ? 0u : slot_cur + (unsigned)WUNIT;
+    slot_cur = slot_u1;
     ++ug;
   };
 
+  bool have_a = false, have_b = false;   // the coming unit's first-tap operands are already on their way (set 0)
   for (int stp = 0, xi = 0; stp < nst; ++stp) {
     // ---- per-step geometry (epilogue cursor)
     const int b = epi_cur.b, s = epi_cur.s, x0 = OW * epi_cur.strip;   // first output column of the strip
@@ -509,7 +548,7 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
       int sl = rb + 2 * wv + i;
       sl = sl >= RSLOT ? sl - RSLOT : sl;
       sl = sl >= RSLOT ? sl - RSLOT : sl;
-      rowa[i] = ring + hi * KHB + sl * ROWB + (j - 1) * 16;      // (chunk 0; advanced by CHB per conv2 chunk)
+      rowa[i] = ring + hi * KHB + sl * ROWB + (j - 1) * 16;      // (chunk 0; the chunk offset travels separately)
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -524,36 +563,44 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
 
     // ---- conv1: four x chunks
     for (int c = 0; c < 4; ++c, ++xi) {
-      const bool has_next = xi + 1 < G, more_in = xi + 2 < G;
+      const bool more_in = xi + 2 < G;
       const unsigned pb = (unsigned)(xi & 1) * PLB;
-      const unsigned bcur = bbase + pb, cnext = cdst + (PLB - pb);
+      const unsigned bcur = bbase + pb, cnext = cdst + (PLB - pb), bnext = bbase + (PLB - pb);
       if (more_in) issue_in_begin();
       set_chunk_rsrc(more_in);
-      (void)has_next;
-      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), bcur, cnext, has_next, more_in, xi == 0, 0, c == 0 && stp > 0);
-      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), bcur, cnext, has_next, more_in, false, 0, false);
-      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 2>(), bcur, cnext, has_next, more_in, false, 0, false);
-      // residual: x~ of this chunk's 16 channels, kept until the output epilogue (accumulator layout)
+      // (vm_extra of unit 0: 4 = the previous chunk end stored four pieces; 2 = the previous unit was a conv2 unit: no raw loads)
+      const int vx0 = c > 0 ? (pending_prev_chunk ? 4 : 0) : (stp > 0 ? 2 : 0);
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 0>(), bcur, cnext, 0u, xi == 0, 0, 0, 0u, have_a, have_b, vx0);
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), bcur, cnext, 0u, false, 0, 0, 0u, true, true, 0);
+      unit(std::integral_constant<int, 1>(), std::integral_constant<int, 2>(), bcur, cnext, 0u, false, 0, c < 3 ? 1 : 0, bnext, true, true, 0);
+      have_a = true;
+      have_b = c < 3;
+      // the previous step's outputs of these 16 channels leave now; then the residual x~ of this chunk takes their registers
+      pending_prev_chunk = pending;
       switch (c) {
         case 0:
+          if (pending) store_part(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 8; ++r) resid[0][nt][r] = rs[nt][r];
           break;
         case 1:
+          if (pending) store_part(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 8; ++r) resid[0][nt][8 + r] = rs[nt][r];
           break;
         case 2:
+          if (pending) store_part(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 8; ++r) resid[1][nt][r] = rs[nt][r];
           break;
         default:
+          if (pending) store_part(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -561,57 +608,73 @@ __global__ void __launch_bounds__(256, 1) resblock_kernel(Params p) {
           break;
       }
     }
+    const bool stored4 = pending;   // (the chunk-3 stores sit between conv1's last unit and conv2's first)
+    pending = false;
 
     // ---- conv1's epilogue, part 0 (channels 0 .. 15 of t: what conv2's first chunk multiplies), then publish it
     if (!(p.abl & 64)) {
-    e1_stage(0);
-    e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
-    e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
-    e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
-    e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+      e1_stage(0);
+      e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+      e1_piece(0, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+      e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+      e1_piece(0, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    }
 
     // ---- conv2: four ring chunks; parts 1 .. 3 of conv1's epilogue ride in chunks 0 .. 2
     for (int c2 = 0; c2 < 4; ++c2) {
       const int e1k = c2 < 3 ? c2 + 1 : 0;
+      const unsigned choff = (unsigned)c2 * CHB;
       if (e1k > 0 && !(p.abl & 64)) e1_stage(e1k);
-      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 0>(), 0u, 0u, false, false, false, e1k, c2 == 0);
-      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 1>(), 0u, 0u, false, false, false, e1k, false);
-      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 2>(), 0u, 0u, false, false, false, 0, false);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rowa[i] += (unsigned)CHB;
+      // the last chunk's last unit fetches the next step's first operands: conv1's first weights and x chunk 0's planes (buffer xi & 1)
+      const unsigned bnext = bbase + (unsigned)(xi & 1) * PLB;
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 0>(), 0u, 0u, choff, false, e1k, 0, 0u, true, c2 > 0, c2 == 0 ? (stored4 ? 6 : 2) : 0);
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 1>(), 0u, 0u, choff, false, e1k, 0, 0u, true, true, 0);
+      unit(std::integral_constant<int, 2>(), std::integral_constant<int, 2>(), 0u, 0u, choff, false, 0, c2 < 3 ? 2 : 1, bnext, true, true, 0);
     }
+    have_a = true;
+    have_b = true;
 
-    // ---- output: rows 8s - 2 + 2wv + nt, columns x0 - 1 + j (j = 1 .. 30)
-    if (!(p.abl & 16))
+    // ---- output: rows 8s - 2 + 2wv + nt, columns x0 - 1 + j (j = 1 .. 30).  The values are finished here (resid <- the sum) and
+    // leave during the next step; a second residual (a body's last block) takes the immediate path.
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int y = 8 * s - 2 + 2 * wv + nt, x = x0 - 1 + j;
       const bool pok = store_ok && j >= 1 && j <= OW && (unsigned)y < (unsigned)p.H && x < p.W;
-      const size_t opix = (size_t)b * p.out_img_pitch + (size_t)(pok ? y : 0) * p.out_row_pitch + (size_t)(pok ? x : 0) * p.out_pix_pitch;
+      const size_t opix = (size_t)b * p.out_img_pitch + (size_t)(pok ? y : 0) * p.out_row_pitch + (size_t)(pok ? x : 0) * p.out_pix_pitch + 4 * hi;
+      ob_prev[nt] = p.out + opix;
+      pok_prev[nt] = pok;
+      if (!(p.abl & 16)) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + 256 + (mt * 32 + 8 * qd + 4 * hi) * 4);
-          f32x4 v;
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(bias_lds + 256 + (mt * 32 + 8 * qd + 4 * hi) * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (acc2[mt][nt][4 * qd + e] * sinv2 + bv[e]) + resid[mt][nt][4 * qd + e];
-          if (pok && !(p.abl & 1)) {
-            const size_t o = opix + 4 * hi + mt * 32 + 8 * qd;
-            if (p.res2) v += *reinterpret_cast<const f32x4*>(p.res2 + o);
-            *reinterpret_cast<f32x4*>(p.out + o) = v;
+            for (int e = 0; e < 4; ++e) resid[mt][nt][4 * qd + e] = (acc2[mt][nt][4 * qd + e] * sinv2 + bv[e]) + resid[mt][nt][4 * qd + e];
+            if (p.res2 != nullptr && pok) {
+              const f32x4 r2 = *reinterpret_cast<const f32x4*>(p.res2 + opix + mt * 32 + 8 * qd);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) resid[mt][nt][4 * qd + e] += r2[e];
+            }
           }
-        }
+      }
     }
+    if (p.res2 != nullptr) wait_vmcnt<0>();   // (rare path -- one block in sixteen: keep the unit waits' counts simple)
+    pending = true;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc1[mt][nt][r] = 0.0f; acc2[mt][nt][r] = 0.0f; }
+  }
+  if (pending) {   // the last step's outputs
+    store_part(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    store_part(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    store_part(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+    store_part(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
   }
   if (p.range_flag != nullptr && !(amax < 65520.0f)) *p.range_flag = 1;   // (rare, idempotent store; inf counts)
 }

@@ -76,8 +76,8 @@ def timed(fn, iters=20):
     return sum(ms) / iters
 
 
-def time_():
-    for hw in (640, 320, 160):
+def time_(sizes=(640, 320, 160)):
+    for hw in sizes:
         x, w1, b1, w2, b2 = make(16, hw, hw, 7)
         out = torch.empty_like(x)
         f = timed(lambda: ops.resblock3x3(x, w1, b1, w2, b2, out=out))
@@ -93,3 +93,5 @@ if __name__ == "__main__":
             check()
         if "time" in what:
             time_()
+        if "time640" in what:
+            time_((640,))

@@ -169,6 +169,33 @@ PY
     diag_rb)    timeout 600 python scripts/diag_resblock.py ${RB_ARGS:-check time} > $O/diag_resblock.log 2>&1; echo "rc=$?" >> $O/diag_resblock.log ;;
     abl_rbk)    (for m in "" ${RBK_MASKS:-8 16 32 40 56 64 120 2} ""; do echo "=== ${m:-in-tree} (C2M_RB_ABL: 1 no stores, 2 no MFMAs, 4 no x loads, 8 no unit-end waits/barriers, 16 no output epilogue, 32 no operand wait before a unit's first tap, 64 no conv1 epilogue)"; C2M_LIB=${m:+$R/build_exp/libc2m_rb$m.so} timeout 200 python scripts/diag_resblock.py time 2>&1 | grep "^{"; done) > $O/abl_resblock_kernel.log 2>&1 ;;
     abl_rbr)    (for m in 0 ${RBR_MASKS:-1 16 64 80} 0; do echo "=== C2M_RB_ABLR=$m (runtime, no dead-code elimination: 1 no output stores, 16 no output epilogue, 64 no conv1 epilogue)"; C2M_RB_ABLR=$m timeout 200 python scripts/diag_resblock.py time 2>&1 | grep "^{"; done) > $O/abl_resblock_runtime.log 2>&1 ;;
+    pmc_rb)     cd /tmp
+                i=0
+                for set in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" \
+                           "SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" \
+                           "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
+                  i=$((i+1))
+                  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $O/pmcrb_$i -o c -- python $R/scripts/diag_resblock.py time640 > $O/pmcrb_$i.log 2>&1
+                  echo "=== pass $i: $set" >> $O/pmc_resblock.txt
+                  grep "^{" $O/pmcrb_$i.log >> $O/pmc_resblock.txt
+                  python $R/scripts/pmc_kernel.py $O/pmcrb_$i "conv" >> $O/pmc_resblock.txt 2>&1
+                  python - $O/pmcrb_$i <<'PY' >> $O/pmc_resblock.txt 2>&1
+import csv, glob, sys, re
+csv.field_size_limit(1 << 30)
+acc = {}
+for fn in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(fn)):
+        k = r["Kernel_Name"]
+        if "conv" not in k: continue
+        m = re.search(r"(c2m::[A-Za-z0-9_:]+(<[^>(]*>)?)", k); k = m.group(1) if m else k[:60]
+        acc.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+for k, v in acc.items():
+    v.sort(); print("   duration ms under the counters:", k, "median", round(v[len(v)//2], 4), "n", len(v))
+PY
+                  rm -rf $O/pmcrb_$i
+                done
+                cd $R ;;
+    test_exp)   C2M_LIB=$R/build_exp/exp/libc2m_hip.so timeout 1500 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16 or loader_matrix or fused_residual" 2>&1 | tail -90 > $O/pytest_experimental.log ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac
