@@ -239,6 +239,9 @@ __device__ __forceinline__ unsigned select_u32(unsigned long long lane_mask, uns
 #ifndef C2M_CORRF_ABL
 #define C2M_CORRF_ABL 0
 #endif
+#ifndef C2M_CORRF_FAST
+#define C2M_CORRF_FAST 1
+#endif
 template <int C, int PF>
 __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
     const _Float16* __restrict__ qpl, const _Float16* __restrict__ rimg, int Hq, int Wq, int Hr, int Wr, int tiles_y, int tiles_x,
@@ -384,13 +387,21 @@ __global__ void __launch_bounds__(NTHR, 2) corr_filter_kernel(
           hq[2] = a2[(r + 1) * TQ * WT];
         }
         const float v = __builtin_fmaf(sum, scale, bias);     // -inf without a candidate
-        // (lane masks + explicit v_cndmask: left to itself hipcc turns the two selects into divergent branches)
-        const unsigned long long m1 = __builtin_amdgcn_fcmpf(v, v1[r], 2 /* ogt */), m2 = __builtin_amdgcn_fcmpf(v, v2[r], 2);
-        const unsigned pa = (pk[r] << 16) | cur, pb = (pk[r] & 0xffffu) | curhi;
-        pk[r] = select_u32(m1, pa, select_u32(m2, pb, pk[r]));
-        v3[r] = __builtin_amdgcn_fmed3f(v2[r], v3[r], v);
-        v2[r] = __builtin_amdgcn_fmed3f(v1[r], v2[r], v);
-        v1[r] = __builtin_fmaxf(v1[r], v);
+        // Round 6: a score that does not beat the lane's THIRD best changes nothing below (med3 / max / selects all return their old
+        // values), and after the first few hundred candidates that is nearly every score -- so the update sits behind ONE compare and
+        // a wave-uniform branch: 5 vector instructions per round instead of 13 when no lane of the wave improves.  On this chip a
+        // wave's vector-ALU instructions cost matrix-pipe time whether or not another wave runs beside it, and
+        // the 14 rounds per ref row were a fifth of the sweep.  (C2M_CORRF_FAST=0: the unconditional update, for A/B builds.)
+        const unsigned long long m3 = __builtin_amdgcn_fcmpf(v, v3[r], 2 /* ogt */);
+        if (!C2M_CORRF_FAST || m3 != 0ull) {
+          // (lane masks + explicit v_cndmask: left to itself hipcc turns the two selects into divergent branches)
+          const unsigned long long m1 = __builtin_amdgcn_fcmpf(v, v1[r], 2 /* ogt */), m2 = __builtin_amdgcn_fcmpf(v, v2[r], 2);
+          const unsigned pa = (pk[r] << 16) | cur, pb = (pk[r] & 0xffffu) | curhi;
+          pk[r] = select_u32(m1, pa, select_u32(m2, pb, pk[r]));
+          v3[r] = __builtin_amdgcn_fmed3f(v2[r], v3[r], v);
+          v2[r] = __builtin_amdgcn_fmed3f(v1[r], v2[r], v);
+          v1[r] = __builtin_fmaxf(v1[r], v);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -196,6 +196,7 @@ PY
                 done
                 cd $R ;;
     test_exp)   C2M_LIB=$R/build_exp/exp/libc2m_hip.so timeout 1500 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16 or loader_matrix or fused_residual" 2>&1 | tail -90 > $O/pytest_experimental.log ;;
+    ab_corrf)   (for lib in "" cf_slow "" cf_slow; do echo "=== ${lib:-in-tree (third-best threshold in front of the top-3 update)} ${lib:+(C2M_CORRF_FAST=0: unconditional update)}"; C2M_LIB=${lib:+$R/build_exp/$lib/libc2m_hip.so} timeout 120 python scripts/abl_corr_filter.py 2>&1 | grep "^{"; C2M_LIB=${lib:+$R/build_exp/$lib/libc2m_hip.so} timeout 300 python bench.py --workload corr --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^{" | python -c "import sys,json; p=json.loads(sys.stdin.read()); print({'configs1_pairs_per_s': round(p['value'],1), 'ms_per_step': round(p['ms_per_step'],3), 'kernels_ms': p['c2m_kernel_ms_per_step']})"; done) > $O/ab_corr_filter_fast.log 2>&1 ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac

@@ -371,12 +371,13 @@ def test_fused_path_size_limit_and_warning(dev):
     assert err < 1e-4, err
     big = torch.zeros((1, 3, 484, 484), device=dev)
     tiny = {k: v[:, :, :8, :8] for k, v in feats.items()}       # (_use_fused looks at dtypes / channel counts only)
-    with pytest.warns(RuntimeWarning, match="module by module"):
-        assert not net._use_fused(big, pre, tiny)
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                           # once per module
-        assert not net._use_fused(big, pre, tiny)
-    assert net._use_fused(torch.zeros((1, 3, 482, 482), device=dev), pre, tiny)
+    with torch.no_grad():                                        # (the fused path is the no_grad path)
+        with pytest.warns(RuntimeWarning, match="module by module"):
+            assert not net._use_fused(big, pre, tiny)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # once per module
+            assert not net._use_fused(big, pre, tiny)
+        assert net._use_fused(torch.zeros((1, 3, 482, 482), device=dev), pre, tiny)
 
 
 def test_cfg3_chain_160_batch2(dev):
