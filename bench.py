@@ -606,20 +606,31 @@ def main():
     last = {}
     bf16 = args.dtype == "bf16"
 
+    class _StepOwner:   # (what RefRestorationModel is to its test(): remembers a pinned full-range flavour)
+        pass
+    step_owner = _StepOwner()
+
     @torch.no_grad()
     def restore_step():
         e = ev[it[0]]
         it[0] += 1
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
-            e[0].record()
-            feats = ext(up, ref)
-            e[1].record()
-            pre, ref_feat = mp(feats, ref)
-            e[2].record()
-            sr = net(lq, pre, ref_feat)
-            e[3].record()
-        last["pre"] = pre
-        return sr
+
+        def whole():   # RefRestorationModel.test(): extractor -> correspondence + VGG taps -> RestorationNet
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                e[0].record()
+                feats = ext(up, ref)
+                e[1].record()
+                pre, ref_feat = mp(feats, ref)
+                e[2].record()
+                sr_ = net(lq, pre, ref_feat)
+                e[3].record()
+            last["pre"] = pre
+            return sr_
+        # one f16 x 2 range check per step, as RefRestorationModel.test() does it (the module forwards' guards nest inside and
+        # skip their own read-backs): $C2M_BENCH_STEP_GUARD=0 restores one check per module (three host syncs per step)
+        if os.environ.get("C2M_BENCH_STEP_GUARD", "1") != "0":
+            return ops.f16_range_guard(step_owner, whole, dev)
+        return whole()
 
     dt, kern, sr = timed(restore_step)
     rank_ms = timed.rank_step_ms

@@ -61,6 +61,10 @@ def _declare(L):
     L.c2m_feature_match_workspace_bytes_c.argtypes = [_i] * 6
     L.c2m_feature_match_skip_table.argtypes = [_i] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     L.c2m_feature_match_index_f32.argtypes = [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp, _sz]
+    L.c2m_feature_match_index_pre_f32.argtypes = [_vp, _vp, _vp] + [_i] * 12 + [_vp, _vp, _vp, _sz, _vp, _vp]
+    L.c2m_feature_match_index_pre_f32.restype = _i
+    L.c2m_feature_normalize_ss_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp]
+    L.c2m_feature_normalize_ss_f32.restype = _i
     L.c2m_feature_match_set_filter.argtypes = [_i]
     L.c2m_conv3x3_set_head_stores.argtypes = [_i]
     L.c2m_feature_match_filter_tables.argtypes = [_i] * 5 + [ctypes.POINTER(ctypes.c_size_t)] * 3 + [ctypes.POINTER(ctypes.c_int)]

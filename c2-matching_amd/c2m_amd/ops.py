@@ -24,17 +24,48 @@ def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
-def feature_normalize(x):
-    """x [B,C,H,W] or [C,H,W] -> per-pixel channel-normalised copy (corres_generation_arch.py:56-58)."""
+class NormalizedFeatures(torch.Tensor):
+    """What `feature_normalize(x, with_sumsq=True)` returns: the normalised map (an ordinary tensor to every consumer) that also
+    carries `.c2m_sumsq` -- its per-pixel sums of squares [B, H*W], formed by the normalisation kernel while the values were in
+    registers.  `feature_match_index_batched` hands them to the library instead of launching a pass over each map; anything
+    derived from the tensor (a slice, a copy, arithmetic) is a plain tensor again and simply loses the shortcut."""
+
+    @staticmethod
+    def wrap(t, ss):
+        r = t.as_subclass(NormalizedFeatures)
+        r.c2m_sumsq = ss
+        r.c2m_version = r._version      # (an in-place write to the map bumps _version: the sums are then stale and are not used)
+        return r
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def feature_normalize(x, with_sumsq=False):
+    """x [B,C,H,W] or [C,H,W] -> per-pixel channel-normalised copy (corres_generation_arch.py:56-58).  with_sumsq: the result is a
+    NormalizedFeatures (same values; carries the per-pixel sums of squares for feature_match_index_batched)."""
     x = _dev_f32(x, "x")
     shp = x.shape
     xb = x.view(1, *shp) if x.dim() == 3 else x
     B, C = xb.shape[0], xb.shape[1]
     out = torch.empty_like(xb)
+    HW = xb.numel() // (B * C)
+    ss = torch.empty((B, HW), dtype=torch.float32, device=x.device) if with_sumsq else None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().c2m_feature_normalize_f32(_stream(), xb.data_ptr(), B, C, xb.numel() // (B * C),
-                                                        out.data_ptr()), "c2m_feature_normalize_f32")
-    return out.view(shp)
+        _lib.check(_lib.lib().c2m_feature_normalize_ss_f32(_stream(), xb.data_ptr(), B, C, HW, out.data_ptr(),
+                                                           ss.data_ptr() if ss is not None else None), "c2m_feature_normalize_ss_f32")
+    out = out.view(shp)
+    return NormalizedFeatures.wrap(out, ss) if with_sumsq else out
+
+
+def _pre_sumsq(t, B, HW):
+    """The sums of squares a NormalizedFeatures carries, if `t` still IS that very tensor (same storage, shape, contiguous)."""
+    ss = getattr(t, "c2m_sumsq", None) if isinstance(t, NormalizedFeatures) else None
+    if ss is None or not t.is_contiguous() or tuple(ss.shape) != (B, HW) or ss.device != t.device or t._version != getattr(t, "c2m_version", -1):
+        return None
+    return ss
 
 
 def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
@@ -57,11 +88,14 @@ def feature_match_index_batched(feat_in, feat_ref, patch_size=3, input_stride=1,
         ws = torch.empty(nbytes, dtype=torch.uint8, device=fi.device)
         idx = torch.empty((B, Hqp, Wqp), dtype=torch.int64, device=fi.device)
         val = torch.empty((B, Hqp, Wqp), dtype=torch.float32, device=fi.device)
+        ss_i, ss_r = _pre_sumsq(feat_in, B, Hq * Wq), _pre_sumsq(feat_ref, B, Hr * Wr)
         with _apply_switch("filter"):
-            _lib.check(L.c2m_feature_match_index_f32(_stream(), fi.data_ptr(), fr.data_ptr(), B, C, Hq, Wq, Hr, Wr, p, si,
-                                                     sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
-                                                     idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes),
-                       "c2m_feature_match_index_f32")
+            _lib.check(L.c2m_feature_match_index_pre_f32(_stream(), fi.data_ptr(), fr.data_ptr(), B, C, Hq, Wq, Hr, Wr, p, si,
+                                                         sr, int(bool(is_norm)), int(bool(norm_input)), int(bool(force_generic)),
+                                                         idx.data_ptr(), val.data_ptr(), ws.data_ptr(), nbytes,
+                                                         ss_i.data_ptr() if ss_i is not None else None,
+                                                         ss_r.data_ptr() if ss_r is not None else None),
+                       "c2m_feature_match_index_pre_f32")
         mfma = (not force_generic) and p == 3 and si == 1 and sr == 1 and C in (64, 128, 256)   # the C-ABI's own dispatch rule
         if return_skip or _corr_diag.enabled:
             # diagnostics only (bench.py's swept-row count, the dedup tests): the duplicate-row table exists only when the

@@ -46,8 +46,10 @@ namespace c2m {
 
 // F.normalize over channels (corres_generation_arch.py:56-58): thread = pixel, coalesced over pixels per channel.
 // Generic version: two passes over the pixel's channel column (the second read mostly misses L2 at 160x160x256).
+// ss_out (or nullptr): the per-pixel sum of squares of the NORMALISED values, the same canonical fmaf chain (c ascending) over
+// the same stored floats as pixel_sumsq_kernel -- what c2m_feature_match_index_pre_f32 takes instead of re-reading the map.
 __global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __restrict__ x, int C, int HW,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, float* __restrict__ ss_out) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
   const float* xb = x + (size_t)blockIdx.y * C * HW + p;
@@ -59,7 +61,13 @@ __global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __r
   }
   const float nrm = sqrtf(ss);
   const float den = nrm > 1e-12f ? nrm : 1e-12f;
-  for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = xb[(size_t)c * HW] / den;
+  float s2 = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const float o = xb[(size_t)c * HW] / den;
+    ob[(size_t)c * HW] = o;
+    s2 = fmaf(o, o, s2);
+  }
+  if (ss_out) ss_out[(size_t)blockIdx.y * HW + p] = s2;
 }
 
 // Same arithmetic (one fmaf chain, c ascending), but the pixel's whole channel column stays in registers between the
@@ -67,7 +75,7 @@ __global__ void __launch_bounds__(256) feature_normalize_kernel(const float* __r
 // (C + a few VGPRs), which is plenty for a pure streaming kernel.
 template <int C>
 __global__ void __launch_bounds__(256, 1) feature_normalize_reg_kernel(const float* __restrict__ x, int HW,
-                                                                        float* __restrict__ out) {
+                                                                        float* __restrict__ out, float* __restrict__ ss_out) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
   const float* xb = x + (size_t)blockIdx.y * C * HW + p;
@@ -80,8 +88,14 @@ __global__ void __launch_bounds__(256, 1) feature_normalize_reg_kernel(const flo
   for (int c = 0; c < C; ++c) ss = fmaf(v[c], v[c], ss);
   const float nrm = sqrtf(ss);
   const float den = nrm > 1e-12f ? nrm : 1e-12f;
+  float s2 = 0.0f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = v[c] / den;
+  for (int c = 0; c < C; ++c) {
+    const float o = v[c] / den;
+    ob[(size_t)c * HW] = o;
+    s2 = fmaf(o, o, s2);
+  }
+  if (ss_out) ss_out[(size_t)blockIdx.y * HW + p] = s2;
 }
 
 // per-pixel sum of squares over channels (canonical fmaf chain, c ascending)
@@ -508,15 +522,19 @@ __global__ void __launch_bounds__(256) pre_offset_kernel(const int64_t* __restri
 // ====================================================================================================================
 using namespace c2m;
 
-extern "C" int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out) {
+extern "C" int c2m_feature_normalize_ss_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out, float* ss_out) {
   if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return C2M_ERR_INVALID_ARG;
   dim3 grid(ceil_div(HW, 256), B);
   hipStream_t st = as_stream(stream);
-  if (C == 256) hipLaunchKernelGGL(feature_normalize_reg_kernel<256>, grid, dim3(256), 0, st, x, HW, out);
-  else if (C == 128) hipLaunchKernelGGL(feature_normalize_reg_kernel<128>, grid, dim3(256), 0, st, x, HW, out);
-  else if (C == 64) hipLaunchKernelGGL(feature_normalize_reg_kernel<64>, grid, dim3(256), 0, st, x, HW, out);
-  else hipLaunchKernelGGL(feature_normalize_kernel, grid, dim3(256), 0, st, x, C, HW, out);
+  if (C == 256) hipLaunchKernelGGL(feature_normalize_reg_kernel<256>, grid, dim3(256), 0, st, x, HW, out, ss_out);
+  else if (C == 128) hipLaunchKernelGGL(feature_normalize_reg_kernel<128>, grid, dim3(256), 0, st, x, HW, out, ss_out);
+  else if (C == 64) hipLaunchKernelGGL(feature_normalize_reg_kernel<64>, grid, dim3(256), 0, st, x, HW, out, ss_out);
+  else hipLaunchKernelGGL(feature_normalize_kernel, grid, dim3(256), 0, st, x, C, HW, out, ss_out);
   return check_launch();
+}
+
+extern "C" int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out) {
+  return c2m_feature_normalize_ss_f32(stream, x, B, C, HW, out, nullptr);
 }
 
 namespace {
@@ -623,6 +641,15 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
                                            int ref_stride, int is_norm, int norm_input, int force_generic,
                                            int64_t* max_idx, float* max_val, void* workspace,
                                            size_t workspace_bytes) {
+  return c2m_feature_match_index_pre_f32(stream, feat_in, feat_ref, B, C, Hq, Wq, Hr, Wr, patch, in_stride, ref_stride, is_norm,
+                                         norm_input, force_generic, max_idx, max_val, workspace, workspace_bytes, nullptr, nullptr);
+}
+
+extern "C" int c2m_feature_match_index_pre_f32(c2m_stream_t stream, const float* feat_in, const float* feat_ref, int B,
+                                               int C, int Hq, int Wq, int Hr, int Wr, int patch, int in_stride,
+                                               int ref_stride, int is_norm, int norm_input, int force_generic,
+                                               int64_t* max_idx, float* max_val, void* workspace,
+                                               size_t workspace_bytes, const float* ss_in_pre, const float* ss_ref_pre) {
   if (!feat_in || !feat_ref || !max_idx || !max_val) return C2M_ERR_INVALID_ARG;
   if (B <= 0 || C <= 0 || patch <= 0 || in_stride <= 0 || ref_stride <= 0) return C2M_ERR_INVALID_ARG;
   if (Hq < patch || Wq < patch || Hr < patch || Wr < patch) return C2M_ERR_INVALID_ARG;
@@ -639,9 +666,12 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
   const int Hrp = (Hr - patch) / ref_stride + 1, Wrp = (Wr - patch) / ref_stride + 1;
   int rc;
   if (is_norm) {
-    hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hr * Wr, 256), B), dim3(256), 0, st, feat_ref, C, Hr * Wr,
-                       ss_ref);
-    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hrp * Wrp, 256), B), dim3(256), 0, st, ss_ref, Hr, Wr, patch,
+    // (ss_*_pre: per-pixel sums of squares the caller already holds -- c2m_feature_normalize_ss_f32 forms them, same chain, while
+    // the normalised values are still in registers -- instead of a pass over the map each)
+    if (!ss_ref_pre)
+      hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hr * Wr, 256), B), dim3(256), 0, st, feat_ref, C, Hr * Wr,
+                         ss_ref);
+    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hrp * Wrp, 256), B), dim3(256), 0, st, ss_ref_pre ? ss_ref_pre : ss_ref, Hr, Wr, patch,
                        ref_stride, Hrp, Wrp, 1, inv);
     if ((rc = check_launch()) != C2M_OK) return rc;
   }
@@ -656,9 +686,10 @@ extern "C" int c2m_feature_match_index_f32(c2m_stream_t stream, const float* fea
   const int filter_on = g_filter_mode < 0 ? filter_env : g_filter_mode;
   const bool use_filter = fast && filter_on && is_norm && c2m::corrf::shapes_ok(B, C, Hq, Wq, Hr, Wr);
   if (norm_input || use_filter) {
-    hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hq * Wq, 256), B), dim3(256), 0, st, feat_in, C, Hq * Wq,
-                       ss_in);
-    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hqp * Wqp, 256), B), dim3(256), 0, st, ss_in, Hq, Wq, patch,
+    if (!ss_in_pre)
+      hipLaunchKernelGGL(pixel_sumsq_kernel, dim3(ceil_div(Hq * Wq, 256), B), dim3(256), 0, st, feat_in, C, Hq * Wq,
+                         ss_in);
+    hipLaunchKernelGGL(patch_norm_kernel, dim3(ceil_div(Hqp * Wqp, 256), B), dim3(256), 0, st, ss_in_pre ? ss_in_pre : ss_in, Hq, Wq, patch,
                        in_stride, Hqp, Wqp, 0, qden);
     if ((rc = check_launch()) != C2M_OK) return rc;
   }

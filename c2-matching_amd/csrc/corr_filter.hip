@@ -74,6 +74,48 @@ __global__ void __launch_bounds__(256) to_nhwc_kernel(const float* __restrict__ 
   }
 }
 
+__device__ __forceinline__ void split2(float x, _Float16& h0, _Float16& h1, bool& bad);
+
+// The query map's two preparation passes in one (round 6): the 64 x 64 transpose tile of to_nhwc_kernel also yields the f16 pieces
+// (split_query_kernel's arithmetic and layout: qpl [B][2][HW][C]) -- every thread splits two runs of 8 channels of one pixel from
+// the tile and stores them as 16-byte pieces.
+__global__ void __launch_bounds__(256) to_nhwc_split_kernel(const float* __restrict__ in, int C, int HW, float* __restrict__ out,
+                                                             _Float16* __restrict__ qpl, int* __restrict__ flags) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* ib = in + (size_t)b * C * HW;
+  float* ob = out + (size_t)b * C * HW;
+  const int p = p0 + tx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[ty + 4 * r][tx] = p < HW ? ib[(size_t)(c0 + ty + 4 * r) * HW + p] : 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int pp = p0 + ty + 4 * r;
+    if (pp < HW) ob[(size_t)pp * C + c0 + tx] = tile[tx][ty + 4 * r];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = threadIdx.x + 256 * it, px = item >> 3, c8 = item & 7;   // 64 pixels x 8 runs of 8 channels
+    const int pp = p0 + px;
+    if (pp < HW) {
+      f16x8 q0, q1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        _Float16 h0, h1;
+        split2(tile[c8 * 8 + e][px], h0, h1, bad);
+        q0[e] = h0; q1[e] = h1;
+      }
+      _Float16* o = qpl + ((size_t)(b * 2) * HW + pp) * C + c0 + c8 * 8;
+      *reinterpret_cast<f16x8*>(o) = q0;
+      *reinterpret_cast<f16x8*>(o + (size_t)HW * C) = q1;
+    }
+  }
+  if (bad) flags[0] = 1;
+}
+
 // 2^14 x = h0 + h1 + e: h0 = rne_f16(2^14 x), h1 = rne_f16(2^14 x - h0); pieces below 2^-14 are flushed to zero here
 __device__ __forceinline__ void split2(float x, _Float16& h0, _Float16& h1, bool& bad) {
   const float xs = x * PIECE_SCALE;   // exact
@@ -672,10 +714,8 @@ int launch(hipStream_t st, const float* fin, const float* fref, int B, int C, in
   static const int dead_tiles = [] { const char* e = getenv("C2M_CORR_DEAD_TILES"); return e ? atoi(e) : 1; }();   // (0: measurement)
   (void)hipMemsetAsync(flags, 0, 32, st);
   (void)hipMemsetAsync(maxcol, 0, sizeof(int) * (size_t)B, st);
-  hipLaunchKernelGGL(to_nhwc_kernel, dim3(ceil_div(HWq, 64), C / 64, B), dim3(256), 0, st, fin, C, HWq, qn);
+  hipLaunchKernelGGL(to_nhwc_split_kernel, dim3(ceil_div(HWq, 64), C / 64, B), dim3(256), 0, st, fin, C, HWq, qn, qpl, flags);
   hipLaunchKernelGGL(to_nhwc_kernel, dim3(ceil_div(HWr, 64), C / 64, B), dim3(256), 0, st, fref, C, HWr, rn);
-  const long long n8 = (long long)B * HWq * (C / 8);
-  hipLaunchKernelGGL(split_query_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, qn, C, HWq, n8, qpl, flags);
   hipLaunchKernelGGL(split_ref_image_kernel, dim3(Hr, nxt, B), dim3(256), 0, st, rn, C, Hr, Wr, nxt, rimg, flags);
   hipLaunchKernelGGL(pixel_eq_kernel, dim3((unsigned)((npix_r + 3) / 4)), dim3(256), 0, st, rn, C, Hr, Wr, npix_r, eq);
   hipLaunchKernelGGL(cand_scale_kernel, dim3(ceil_div(Hrp * Wrp, 256), B), dim3(256), 0, st, inv, eq, npix_r, Hr, Wr, Hrp, Wrp, sc,

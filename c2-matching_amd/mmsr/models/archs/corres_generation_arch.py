@@ -105,8 +105,9 @@ class CorrespondenceGenerationArch(nn.Module):
     def match(self, dense_features):
         """-> (max_idx int64 [B, h-2, w-2], max_val float32 [B, h-2, w-2]) for the whole batch."""
         # (.float(): under autocast the extractor hands over bf16 features; matching runs in float32)
-        feat_in = _ops.feature_normalize(dense_features['dense_features1'].float())
-        feat_ref = _ops.feature_normalize(dense_features['dense_features2'].float())
+        # (with_sumsq: the normalisation kernel also leaves the per-pixel sums of squares the matcher's patch norms need)
+        feat_in = _ops.feature_normalize(dense_features['dense_features1'].float(), with_sumsq=True)
+        feat_ref = _ops.feature_normalize(dense_features['dense_features2'].float(), with_sumsq=True)
         return _ops.feature_match_index_batched(feat_in, feat_ref, self.patch_size, self.stride, self.stride,
                                                 is_norm=True, norm_input=True)
 

@@ -208,8 +208,18 @@ class RefRestorationModel(BaseModel):
     def test(self):
         self.net_g.eval()
         with torch.no_grad():
-            self._correspondence()
-            self.output = self.net_g(self.img_in_lq, self.pre_offset, self.img_ref_feat)
+            def whole():
+                self._correspondence()
+                return self.net_g(self.img_in_lq, self.pre_offset, self.img_ref_feat)
+            if self.img_in_lq.is_cuda:
+                # ONE f16 x 2 range check for the whole inference step (extractor, VGG taps, RestorationNet): the module
+                # forwards' own guards nest inside it and skip their read-backs -- one 4-byte device-to-host sync per step
+                # instead of three (each one drains the GPU queue: ~0.3 ms of a 139 ms configs[2] step).  On overflow the whole
+                # step is recomputed on the full-range flavour and this model keeps it (ops.f16_range_guard).
+                from c2m_amd import ops as _ops
+                self.output = _ops.f16_range_guard(self, whole, self.img_in_lq.device)
+            else:
+                self.output = whole()
         if self.is_train:
             self.net_g.train()
         return self.output

@@ -70,6 +70,10 @@ int c2m_profile_collect(float* ms, int* kernel_id, int capacity, int* count);
 
 /* x, out: [B][C][HW] fp32.  out[b,c,p] = x[b,c,p] / max(||x[b,:,p]||_2, 1e-12).  In-place allowed. */
 int c2m_feature_normalize_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out);
+/* The same, and ss_out [B][HW] (or NULL) = sum over c of out[b,c,p]^2 as ONE fmaf chain, c ascending, over the stored floats: the
+ * per-pixel sums of squares c2m_feature_match_index_pre_f32 needs for its patch norms (ref_map_util.py:63, :80), formed while the
+ * values are in registers instead of by another pass over the map (round 6: two of the correlation's preparation launches). */
+int c2m_feature_normalize_ss_f32(c2m_stream_t stream, const float* x, int B, int C, int HW, float* out, float* ss_out);
 
 /* Bytes of scratch c2m_feature_match_index_f32 needs for these shapes (patch norms of both maps, duplicate-row table, and
  * the pre-filter's channels-last copies / f16 pieces / candidate lists, sized for C = 256). */
@@ -131,6 +135,13 @@ int c2m_feature_match_index_f32(c2m_stream_t stream, const float* feat_in, const
                                 int Hq, int Wq, int Hr, int Wr, int patch, int in_stride, int ref_stride,
                                 int is_norm, int norm_input, int force_generic, int64_t* max_idx, float* max_val,
                                 void* workspace, size_t workspace_bytes);
+/* The same with the per-pixel sums of squares of one or both maps handed in (ss_in_pre [B][Hq*Wq], ss_ref_pre [B][Hr*Wr]: what
+ * c2m_feature_normalize_ss_f32 wrote next to the normalised maps; NULL = computed here).  They must be the canonical chain over
+ * THESE maps' values (fmaf, c ascending) -- the patch norms, and with them the index map's bit-exactness, depend on it. */
+int c2m_feature_match_index_pre_f32(c2m_stream_t stream, const float* feat_in, const float* feat_ref, int B, int C,
+                                    int Hq, int Wq, int Hr, int Wr, int patch, int in_stride, int ref_stride,
+                                    int is_norm, int norm_input, int force_generic, int64_t* max_idx, float* max_val,
+                                    void* workspace, size_t workspace_bytes, const float* ss_in_pre, const float* ss_ref_pre);
 
 /*
  * max_idx [B][h-2][w-2] int64 (h, w = feature-map size of BOTH maps)  ->

@@ -377,6 +377,30 @@ def test_filter_mode_reaches_launches_from_worker_threads(env, dev):
     assert "corr_filter" in seen["filter"], seen
 
 
+def test_sums_of_squares_from_the_normalisation_kernel_change_nothing(env, dev):
+    """Round 6: `feature_normalize(x, with_sumsq=True)` leaves the per-pixel sums of squares (the canonical fmaf chain over the
+    stored normalised values) for the matcher, which then skips its own pass over each map.  Same normalised maps, same sums as
+    the stand-alone pass (the values max_val is built from: query and ref patch norms), same index maps and values bit for bit -- and an in-place write to the map switches the shortcut off."""
+    ops, oracle, synth = env
+    a = _t(synth.gaussish((2, 256, 30, 26), 901), dev)
+    r = _t(synth.gaussish((2, 256, 34, 40), 902), dev)
+    n1, n2 = ops.feature_normalize(a), ops.feature_normalize(r)
+    s1, s2 = ops.feature_normalize(a, with_sumsq=True), ops.feature_normalize(r, with_sumsq=True)
+    assert torch.equal(n1, s1) and torch.equal(n2, s2)
+    assert tuple(s1.c2m_sumsq.shape) == (2, 30 * 26) and float((s1.c2m_sumsq - 1.0).abs().max()) < 1e-5   # (normalised pixels)
+    i0, v0 = ops.feature_match_index_batched(n1, n2, 3, 1, 1, True, True)
+    i1, v1 = ops.feature_match_index_batched(s1, s2, 3, 1, 1, True, True)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    for b in range(2):
+        oi, ov = oracle.feature_match_index(oracle.feature_normalize(a[b].cpu().numpy()), oracle.feature_normalize(r[b].cpu().numpy()), 3, 1, 1, True, True)
+        assert np.array_equal(i1[b].cpu().numpy(), oi) and np.array_equal(v1[b].cpu().numpy(), ov)
+    s2[0, :, 20:, :] = s2[0, :, 20:21, :]                   # an in-place edit: the carried sums are stale now and must not be used
+    assert ops._pre_sumsq(s2, 2, 34 * 40) is None
+    i2, v2 = ops.feature_match_index_batched(s1, s2, 3, 1, 1, True, True)
+    i3, v3 = ops.feature_match_index_batched(n1, torch.Tensor(s2.clone()), 3, 1, 1, True, True)
+    assert torch.equal(i2, i3) and torch.equal(v2, v3)
+
+
 def test_prefilter_leaves_its_domain_through_the_exact_sweep(env, dev):
     """|x| >= 3.99 (f16 pieces would overflow), a degenerate all-zero ref patch (1 / (|r| + 1e-5) > 2) and a NaN each raise the
     device flag; the result is then the exact sweep's -- the oracle's -- without a host round trip."""
