@@ -197,6 +197,20 @@ PY
                 cd $R ;;
     test_exp)   C2M_LIB=$R/build_exp/exp/libc2m_hip.so timeout 1500 python -m pytest tests/test_conv_gpu.py -m gpu -q -rA -k "wino16 or loader_matrix or fused_residual" 2>&1 | tail -90 > $O/pytest_experimental.log ;;
     ab_corrf)   (for lib in "" cf_slow "" cf_slow; do echo "=== ${lib:-in-tree (third-best threshold in front of the top-3 update)} ${lib:+(C2M_CORRF_FAST=0: unconditional update)}"; C2M_LIB=${lib:+$R/build_exp/$lib/libc2m_hip.so} timeout 120 python scripts/abl_corr_filter.py 2>&1 | grep "^{"; C2M_LIB=${lib:+$R/build_exp/$lib/libc2m_hip.so} timeout 300 python bench.py --workload corr --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "^{" | python -c "import sys,json; p=json.loads(sys.stdin.read()); print({'configs1_pairs_per_s': round(p['value'],1), 'ms_per_step': round(p['ms_per_step'],3), 'kernels_ms': p['c2m_kernel_ms_per_step']})"; done) > $O/ab_corr_filter_fast.log 2>&1 ;;
+    pmc_conv_ta) cd /tmp
+                i=0
+                for set in "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE" \
+                           "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum GRBM_GUI_ACTIVE" \
+                           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+                           "TD_TD_BUSY_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do
+                  i=$((i+1))
+                  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $O/pmcta_$i -o c -- python $R/scripts/bench_conv.py --algo split16 --only "64->64 @640" --iters 4 > $O/pmcta_$i.log 2>&1
+                  echo "=== pass $i: $set" >> $O/pmc_conv_ta.txt
+                  grep "^{'layer" $O/pmcta_$i.log >> $O/pmc_conv_ta.txt
+                  python $R/scripts/pmc_kernel.py $O/pmcta_$i "conv3x3_split_kernel" >> $O/pmc_conv_ta.txt 2>&1
+                  rm -rf $O/pmcta_$i
+                done
+                cd $R ;;
     diag_pf1)   C2M_CORR_PF=1 timeout 600 python scripts/diag_corr_filter.py > $O/diag_corr_filter_pf1.log 2>&1 ;;
     *)          echo "unknown stage $stage" ;;
   esac
