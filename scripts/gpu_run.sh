@@ -91,6 +91,16 @@ for stage in "$@"; do
     prof)       cd /tmp
                 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_step -o step -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_step.log 2>&1
                 cd $R ;;
+    ab_mix)     (cd scripts/ubench && timeout 120 ./split_mix_check) > $O/split_mix_check.log 2>&1
+                (timeout 300 python scripts/diag_split_bits.py > $O/bits_mix.log 2>&1; C2M_LIB=$R/build_exp/nomix/libc2m_hip.so timeout 300 python scripts/diag_split_bits.py > $O/bits_nomix.log 2>&1
+                 grep "^{" $O/bits_mix.log > $O/bits_a.txt; grep "^{" $O/bits_nomix.log > $O/bits_b.txt
+                 echo "lines: $(wc -l < $O/bits_a.txt) / $(wc -l < $O/bits_b.txt); differing lines: $(diff $O/bits_a.txt $O/bits_b.txt | grep -c '^<')") > $O/bits_diff.txt 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_mix_layers.log 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_mix_step.log 2>&1 ;;
+    prof_cfg5)  cd /tmp
+                timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
+                cp $(find $O/prof_cfg5 -name '*kernel_stats.csv' | head -1) $O/cfg5_kernel_stats.csv; rm -rf $O/prof_cfg5
+                cd $R ;;
     pmc)        cd /tmp
                 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace -f csv -d $O/pmc_mfma -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_mfma.log 2>&1
                 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $O/pmc_fetch -o step -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_fetch.log 2>&1
