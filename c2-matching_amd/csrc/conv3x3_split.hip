@@ -526,6 +526,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   };
   auto load_b = [&](auto setc, auto dyc, auto dxc, auto kc, unsigned bcur) __attribute__((always_inline)) {   // bcur = bbase + plane buffer
     constexpr int SET = decltype(setc)::value, DY = decltype(dyc)::value, DX = decltype(dxc)::value, K = decltype(kc)::value;
+    // (ablation 2048, timing only: the B operand of pixel row nt = 0 at kernel row dy >= 1 is the one row nt = 1 read at dy - 1 -- skip
+    // the re-read, 12 of a chunk's 36 B reads: what holding a unit's four pixel rows in registers would save)
+    if constexpr ((ABL & 2048) != 0 && (K % NT) == 0 && DY >= 1) return;
     lds_read128<(K / NT) * 2 * HALFB + ((K % NT + DY) * HWc + DX) * 16>(Bq[SET][K / NT][K % NT], bcur);
   };
 
@@ -544,6 +547,24 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  // ABL & 1024 (-DC2M_SPLIT_TRACE builds only; scripts/trace_split.py): a timeline of two tiles per wave -- s_memtime just before and just
+  // after every unit-end barrier and after the epilogue, kept in the 64 lanes of ONE register and stored once, at the kernel's
+  // end, to Params::mask_out [workgroup][wave][64]; lanes 62 / 63 carry XCC_ID / HW_ID (which CU the workgroup ran on).  Every stamp sits
+  // where lgkmcnt is already zero, so the s_waitcnt it needs costs the timestamp's own latency only.
+  unsigned trace_v = 0u;
+  int trace_it = -1;   // tile slot (0 / 1) being traced, or -1
+  auto stamp = [&](int ev) __attribute__((always_inline)) {
+    if constexpr ((ABL & 1024) != 0) {
+      if (trace_it >= 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        const unsigned tl = (unsigned)t;
+        const int ln = trace_it * 26 + ev;
+        trace_v = l == ln ? tl : trace_v;   // (v_writelane_b32 with two SGPR operands violates gfx9's constant-bus limit)
+      }
+    }
+  };
 
   // ------------------------------------------------------------------------------------------------------------------
   // prologue: the raw pieces of chunk 0 and the weights of unit 0
@@ -611,6 +632,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
   static_assert(NRAW_W == 6, "two split rounds per unit");
   unsigned slot_cur = 0u;   // ring slot (byte offset) of the current unit
   for (int it = 0, gc = 0; it < ntl; ++it) {
+    if constexpr ((ABL & 1024) != 0) trace_it = (it >= p.co_off && it < p.co_off + 2 && p.nchunks <= 4) ? it - p.co_off : -1;
     for (int c = 0; c < p.nchunks; ++c, ++gc) {
       // PIPE: the registers hold chunk gc+1 (if any); they re-load with chunk gc+2.  Else: they hold chunk gc, re-load with gc+1
       const bool has_next = PIPE ? gc + 1 < G : true;
@@ -740,7 +762,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             if ((ABL & 128) && c == 0 && dy == 0) wait_vmcnt<4 + NW_W + 16>();
             else wait_vmcnt<4 + NW_W>();
           } else wait_vmcnt<0>();
+          stamp(2 * (3 * c + dy));
           __builtin_amdgcn_s_barrier();
+          stamp(2 * (3 * c + dy) + 1);
         }
         slot_cur = slot_cur == (unsigned)((NRING - 1) * WUNIT) ? 0u : slot_cur + (unsigned)WUNIT;
       });
@@ -750,6 +774,53 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     // ----------------------------------------------------------------------------------------------------------------
     const int b = epi_tc.b, y0 = epi_tc.ty * THY, x0 = epi_tc.tx * TWX;
     tc_next(epi_tc);
+    // Channels-last tiles WITH A RESIDUAL that lie inside the image with all their channels (every tile of the bodies' second convolutions
+    // but the map's last row / column of tiles): a straight-line epilogue.  Row 0's eight residual pieces are requested HERE, in front of the
+    // bias / activation arithmetic, row 1's before row 0 is stored.  (The generic path below fetches each piece behind its own branches
+    // and between two stores that may alias it: hipcc serialises that into 16 x (load, s_waitcnt vmcnt(0), add, store), and on gfx9 that
+    // wait also drains the previous store -- 21 000 cycles per tile against 7 300 without a residual, scripts/trace_split.py.)
+    constexpr bool EPI_FAST = MODE == 0 && !IO16 && (ABL & (64 | 512)) == 0;
+    bool fast = false;
+    size_t fpix = 0;
+    f32x4 rv[MT][4];   // one pixel row's pieces at a time (both rows: 64 registers, and hipcc spills)
+    auto res_load = [&](const float* r, int nt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) rv[mt][qd] = *reinterpret_cast<const f32x4*>(r + fpix + (size_t)nt * p.out_row_pitch + mt * 32 + 8 * qd);
+    };
+    auto res_add = [&](int nt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt][nt][4 * qd + e] += rv[mt][qd][e];
+    };
+    // the same for bf16 tensors (configs[4]'s bodies: bf16 output, bf16 residual): both rows' four 16-byte pieces per lane, requested here
+    typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+    constexpr bool EPI_FAST16 = IO16 && (ABL & (64 | 512)) == 0;   // (IO16 implies FL == 1, MODE == 0)
+    bool fast16 = false;
+    bf16x8r hres[NT][MT][2];
+    if constexpr (EPI_FAST16) {
+      fast16 = (p.io_flags & 6) == 6 && p.res1 != nullptr && cb * MW + MW <= p.Cout && y0 + THY <= p.H && x0 + TWX <= p.W;
+      if (fast16) {
+        const __bf16* rb = reinterpret_cast<const __bf16*>(p.res1) + (size_t)b * p.out_img_pitch + (size_t)(y0 + 2 * wv) * p.out_row_pitch +
+                           (size_t)(x0 + j) * p.out_pix_pitch + cb * MW + 8 * hi;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) hres[nt][mt][k] = *reinterpret_cast<const bf16x8r*>(rb + (size_t)nt * p.out_row_pitch + mt * 32 + 16 * k);
+      }
+    }
+    if constexpr (EPI_FAST) {
+      fast = (p.res1 != nullptr || p.res2 != nullptr) && p.out_vec4 != 0 && cb * MW + MW <= p.Cout && y0 + THY <= p.H && x0 + TWX <= p.W &&
+             (FL != 1 || (p.io_flags & 14) == 0);   // (without a residual the generic path's stores measured 1 % faster)
+      fpix = (size_t)b * p.out_img_pitch + (size_t)(y0 + 2 * wv) * p.out_row_pitch + (size_t)(x0 + j) * p.out_pix_pitch + co_lane;
+      if (fast && p.res1 != nullptr) res_load(p.res1, 0);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -851,6 +922,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             }
             if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
+      } else if (EPI_FAST && fast) {
+        static_assert(NT == 2, "two pixel rows per wave");
+        auto store_row = [&](int nt) __attribute__((always_inline)) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+              *reinterpret_cast<f32x4*>(p.out + fpix + (size_t)nt * p.out_row_pitch + mt * 32 + 8 * qd) = v;
+            }
+        };
+        // row 0's pieces were requested at the top of the epilogue; row 1's go out before row 0 is stored
+        if (p.res1 != nullptr) { res_add(0); res_load(p.res1, 1); }
+        if (p.res2 != nullptr) {   // (the stage input on a body's last block)
+          if (p.res1 != nullptr) res_add(1);
+          res_load(p.res2, 0); res_add(0);
+          res_load(p.res2, 1);
+        }
+        store_row(0);
+        res_add(1);
+        store_row(1);
       } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -893,7 +987,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
                           for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += c[e]; }
                         }
                       };
-                      if (p.res1) res(p.res1, (p.io_flags & 4) != 0);
+                      if (EPI_FAST16 && fast16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)hres[nt][mt][k][e];
+                      } else if (p.res1) res(p.res1, (p.io_flags & 4) != 0);
                       if (p.res2) res(p.res2, (p.io_flags & 8) != 0);
                       bf16x8v h;
 #pragma unroll
@@ -1026,9 +1123,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    stamp(24);
   }
   if constexpr (FL == 2) {
     if (p.range_flag != nullptr && !(amax < 65520.0f)) *p.range_flag = 1;   // (rare, idempotent store; inf counts)
+  }
+  if constexpr ((ABL & 1024) != 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)), hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_XCC_ID[3:0], HW_REG_HW_ID
+    asm volatile("v_writelane_b32 %0, %1, 62\n\tv_writelane_b32 %0, %2, 63" : "+v"(trace_v) : "s"(xcc), "s"(hwid));
+    reinterpret_cast<unsigned*>(p.mask_out)[((size_t)blockIdx.x * 4 + wv) * 64 + l] = trace_v;
   }
 }
 
@@ -1152,6 +1255,34 @@ static int launch_split_mode(hipStream_t st, const Params& p, dim3 grid) {
         case 112: go(&split::conv3x3_split_kernel<NP, 2, 0, 112>, done_abl[12]); break;
         case 256: go(&split::conv3x3_split_kernel<NP, 2, 0, 256>, done_abl[0]); break;
         case 512: { static unsigned long long d512 = 0; go(&split::conv3x3_split_kernel<NP, 2, 0, 512>, d512); break; }
+#ifdef C2M_SPLIT_TRACE
+        case 2048: { static unsigned long long d2048 = 0; go(&split::conv3x3_split_kernel<NP, 2, 0, 2048>, d2048); break; }
+        case 1024: {   // timeline build: RIGHT results; every launch appends [int grid][int tpw][grid x 4 x 64 words] to $C2M_SPLIT_TRACE_FILE
+          static unsigned long long d1024 = 0;
+          static unsigned* tbuf = nullptr;
+          const size_t tb = (size_t)grid.x * 4 * 64 * sizeof(unsigned);
+          if (!tbuf && hipMalloc(&tbuf, 4096 * 4 * 64 * sizeof(unsigned)) != hipSuccess) return C2M_ERR_LAUNCH;
+          if (grid.x > 4096) return C2M_ERR_UNSUPPORTED;
+          (void)hipMemsetAsync(tbuf, 0, tb, st);
+          Params q = p;
+          q.mask_out = reinterpret_cast<float*>(tbuf);
+          const char* e = getenv("C2M_SPLIT_TRACE_IT");
+          q.co_off = e ? atoi(e) : 20;
+          if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&split::conv3x3_split_kernel<NP, 2, 0, 1024>), ldsb, d1024)) == C2M_OK) {
+            hipLaunchKernelGGL((split::conv3x3_split_kernel<NP, 2, 0, 1024>), grid, dim3(256), ldsb, st, q);
+            const char* fn = getenv("C2M_SPLIT_TRACE_FILE");
+            if (fn) {
+              (void)hipStreamSynchronize(st);
+              unsigned* h = (unsigned*)malloc(tb);
+              (void)hipMemcpy(h, tbuf, tb, hipMemcpyDeviceToHost);
+              FILE* f = fopen(fn, "ab");
+              if (f) { const int hd[4] = {(int)grid.x, p.tpw, p.res1 != nullptr, p.H}; fwrite(hd, 4, 4, f); fwrite(h, 1, tb, f); fclose(f); }
+              free(h);
+            }
+          }
+          break;
+        }
+#endif
         default: fprintf(stderr, "c2m: unknown C2M_SPLIT_ABL mask\n"); return C2M_ERR_INVALID_ARG;
       }
       return rc;

@@ -97,6 +97,39 @@ for stage in "$@"; do
                  echo "lines: $(wc -l < $O/bits_a.txt) / $(wc -l < $O/bits_b.txt); differing lines: $(diff $O/bits_a.txt $O/bits_b.txt | grep -c '^<')") > $O/bits_diff.txt 2>&1
                 (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_mix_layers.log 2>&1
                 (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_mix_step.log 2>&1 ;;
+    ub_ta)      (cd scripts/ubench && timeout 300 ./vmem_ta_cost) > $O/ubench_vmem_ta_cost.log 2>&1
+                cd /tmp
+                for fp in 0 1; do
+                  timeout 300 rocprofv3 --pmc TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace -f csv -d $O/pmc_ubta$fp -o c -- $R/scripts/ubench/vmem_ta_cost $fp > $O/pmc_ubta$fp.log 2>&1
+                  echo "=== footprint $fp (0 = L2, 1 = HBM)" >> $O/ubench_vmem_ta_pmc.txt
+                  python $R/scripts/pmc_kernel.py $O/pmc_ubta$fp "void k<" >> $O/ubench_vmem_ta_pmc.txt 2>&1
+                  rm -rf $O/pmc_ubta$fp
+                done
+                cd $R ;;
+    abl512)     (for abl in 0 512 0 512; do echo "=== C2M_SPLIT_ABL=$abl (512: quad address pattern for stores and residual loads -- lanes 4q..4q+3 cover 64 contiguous bytes)"; C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only "64->64" --iters 20 2>&1 | grep "^{'layer"; done) > $O/abl512.log 2>&1 ;;
+    trace)      (C2M_LIB=$R/build_exp/trace/libc2m_hip.so C2M_SPLIT_ABL=1024 C2M_SPLIT_TRACE_IT=4 timeout 300 python scripts/trace_split.py 640 16
+                 C2M_LIB=$R/build_exp/trace/libc2m_hip.so C2M_SPLIT_ABL=1024 C2M_SPLIT_TRACE_IT=1 timeout 300 python scripts/trace_split.py 160 16
+                 for lib in "" $R/build_exp/trace/libc2m_hip.so; do echo "=== timing, C2M_LIB=$lib"; C2M_LIB=$lib C2M_SPLIT_ABL=${lib:+1024} timeout 200 python scripts/bench_conv.py --algo split16 --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/trace_split.log 2>&1 ;;
+    power)      (rocm-smi -M 2>&1 | grep -i "power\|GPU"; rocm-smi -P -c -t --json 2>&1 | cut -c1-900
+                 BC="python $R/scripts/bench_conv.py --algo split16 --iters 6000"
+                 bash scripts/power_probe.sh "$BC --only 'body 64->64 @640'" "f16 x 2 body 64->64 @640, N(0,1) data"
+                 bash scripts/power_probe.sh "$BC --only 'body+res 64->64 @640'" "f16 x 2 body+res 64->64 @640, N(0,1) data"
+                 bash scripts/power_probe.sh "$BC --only 'body 64->64 @640' --data zeros" "f16 x 2 body 64->64 @640, all-zero data"
+                 C2M_SPLIT_ABL=48 bash scripts/power_probe.sh "$BC --only 'body 64->64 @640'" "the same without its MFMAs and operand reads (C2M_SPLIT_ABL=48)"
+                 C2M_SPLIT_ABL=47 bash scripts/power_probe.sh "$BC --only 'body 64->64 @640'" "MFMAs only: no loads, split, operand reads, barriers (C2M_SPLIT_ABL=47)") > $O/power_probe.log 2>&1 ;;
+    power2)     (C2M_SPLIT_ABL=32 bash scripts/power_probe.sh "python $R/scripts/bench_conv.py --algo split16 --iters 6000 --only 'body 64->64 @640'" "f16 x 2 body 64->64 @640 without the operand ds_reads (C2M_SPLIT_ABL=32)"
+                 bash scripts/power_probe.sh "python $R/scripts/bench_conv.py --algo bf16 --io16 --iters 6000 --only 'body 64->64 @640'" "bf16 tensors, one product: body 64->64 @640"
+                 bash scripts/power_probe.sh "python $R/bench.py --workload corr --steps 400 --warmup 3 --no-cpu-baseline" "correlation stage alone (bench.py --workload corr)" 12 8
+                 bash scripts/power_probe.sh "python $R/scripts/bench_dcn_nhwc.py --iters 400" "DCNv2 forwards (three layers, fp32 and f16 x 2 in turn)" 16 6
+                 bash scripts/power_probe.sh "python $R/bench.py --steps 120 --warmup 3 --no-cpu-baseline --no-alt" "the whole configs[2] step, back to back" 40 10) > $O/power_probe2.log 2>&1 ;;
+    abl2048)    (for abl in 0 2048 32 0 2048; do echo "=== C2M_SPLIT_ABL=$abl (2048: 12 of a chunk's 36 B-operand reads skipped -- the re-reads of a pixel row the other accumulator row read one kernel row earlier; 32: no operand reads at all)"; C2M_LIB=$R/build_exp/trace/libc2m_hip.so C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only "64->64" --iters 20 2>&1 | grep "^{'layer"; done
+                 C2M_SPLIT_ABL=2048 bash scripts/power_probe.sh "C2M_LIB=$R/build_exp/trace/libc2m_hip.so python $R/scripts/bench_conv.py --algo split16 --iters 6000 --only 'body 64->64 @640'" "f16 x 2 body 64->64 @640, 12 of 36 B reads skipped (C2M_SPLIT_ABL=2048)") > $O/abl2048.log 2>&1 ;;
+    ab_epi)     (timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -x 2>&1 | tail -5) > $O/ab_epi_tests.log 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_epi_layers.log 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_epi_step.log 2>&1 ;;
+    ab_epi16)   (timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -x -k "bf16 or io16 or cfg5 or autocast" 2>&1 | tail -5) > $O/ab_epi16_tests.log 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --io16 --batch 4 --only "@1280" --iters 20 2>&1 | grep "^{'layer"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --io16 --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_epi16_layers.log 2>&1
+                (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --lr 320 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_epi16_step.log 2>&1 ;;
     prof_cfg5)  cd /tmp
                 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
                 cp $(find $O/prof_cfg5 -name '*kernel_stats.csv' | head -1) $O/cfg5_kernel_stats.csv; rm -rf $O/prof_cfg5
