@@ -541,6 +541,36 @@ def test_conv3x3_wino16_full_size_body_conv(experimental, ops, dev, algo):
     assert float((got[sub][:, :, 2:, 2:].double() - want).abs().max()) < 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 45, 70), (1, 64, 96), (3, 8, 32), (1, 200, 130)])
+def test_conv3x3_residual_epilogue_in_place_and_edges(ops, dev, shape):
+    """The straight-line residual epilogue of the split kernel (tiles inside the image: residual pieces requested in batches, stores
+    without branches; edge tiles: the generic path): maps with interior AND edge tiles, one and two residuals, fp32 and bf16 tensors --
+    against float64, and IN PLACE (`out` is the residual tensor itself: every lane must have read its pieces before it overwrites them),
+    bit-identical to the out-of-place result."""
+    B, H, W = shape
+    x = _cl(_rand((B, 64, H, W), dev, 900 + H))
+    w, b = _rand((64, 64, 3, 3), dev, 901, 1.0 / 24.0), _rand((64,), dev, 902)
+    r1, r2 = _cl(_rand((B, 64, H, W), dev, 903)), _cl(_rand((B, 64, H, W), dev, 904))
+    for algo in ("split16", "split"):
+        for res in ((r1,), (r1, r2), (None, r2)):
+            kw = dict(act=ops.ACT_RELU, res1=res[0], res2=res[1] if len(res) > 1 else None, algo=algo)
+            got = ops.conv3x3(x, w, b, **kw)
+            want = _ref([x], w, b, 1, 0.1, [r for r in res if r is not None])
+            assert float((got.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max())), (algo, len(res))
+            tgt = (res[0] if res[0] is not None else res[1]).clone(memory_format=torch.preserve_format)
+            kw2 = dict(kw)
+            kw2["res1" if res[0] is not None else "res2"] = tgt
+            out = ops.conv3x3(x, w, b, out=tgt, **kw2)
+            assert out.data_ptr() == tgt.data_ptr() and torch.equal(tgt, got), (algo, len(res))
+    xb, rb = x.to(torch.bfloat16), r1.to(torch.bfloat16)                 # configs[4]'s body: bf16 source, residual and output
+    got = ops.conv3x3(xb, w, b, res1=rb, algo="bf16", out_dtype=torch.bfloat16)
+    want = F.conv2d(xb.double(), w.to(torch.bfloat16).double(), b.double(), padding=1) + rb.double()
+    assert float((got.double() - want).abs().max()) < 2.0 ** -7 * max(1.0, float(want.abs().max()))   # one bf16 rounding of the sum
+    tgt = rb.clone(memory_format=torch.preserve_format)
+    ops.conv3x3(xb, w, b, res1=tgt, out=tgt, algo="bf16")
+    assert torch.equal(tgt, got)
+
+
 @pytest.mark.parametrize("algo", SPLIT_ALGOS)
 def test_conv3x3_split_output_modes(ops, dev, algo):
     """PixelShuffle(2), planar NCHW, ReLU + MaxPool2d(2, 2), a channel-slice source and a strided (bordered) destination."""
