@@ -345,6 +345,52 @@ def cpu_one_thread(ext, mp, net, lq, up, ref):
                       f"RestorationNet 1/16 of the pixels x 16 = {t_rest:.1f} s"}
 
 
+def power_probe(step, sync, it, seconds=3.0):
+    """Socket power / shader clock (rocm-smi) while `step` runs back to back for ~`seconds` s: {"socket_w": mean, "socket_w_max", "cap_w",
+    "sclk_mhz": mean, "samples"} or {"error": ...}.  A helper thread polls rocm-smi; the main thread keeps the queue full."""
+    import re, shutil, subprocess, threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([exe, "-P", "-c", "--json"], capture_output=True, text=True, timeout=10).stdout
+                d = next(iter(json.loads(out[out.index("{"):]).values()))
+                w = [float(v) for k, v in d.items() if "Package Power" in k]
+                c = [int(re.sub(r"\D", "", v)) for k, v in d.items() if k.startswith("sclk clock speed")]
+                if w and c:
+                    samples.append((w[0], c[0]))
+            except Exception:  # noqa: BLE001
+                return
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            it[0] = 0
+            step()
+            sync()
+        stop.set()
+        th.join(timeout=15)
+        busy = [x for x in samples if x[0] > 600.0] or samples
+        if not busy:
+            return {"error": "no sample"}
+        cap = None
+        try:
+            out = subprocess.run([exe, "-M", "--json"], capture_output=True, text=True, timeout=10).stdout
+            cap = [float(v) for v in next(iter(json.loads(out[out.index("{"):]).values())).values()][0]
+        except Exception:  # noqa: BLE001
+            pass
+        return {"socket_w": _rnd(sum(a for a, _ in busy) / len(busy), 0), "socket_w_max": max(a for a, _ in busy), "cap_w": cap,
+                "sclk_mhz": int(sum(b for _, b in busy) / len(busy)), "samples": len(busy), "what": "rocm-smi while the step runs back to back"}
+    except Exception as e:  # noqa: BLE001
+        stop.set()
+        return {"error": repr(e)}
+
+
 def cpu_baseline_corr(h, C, budget_s=12.0):
     """configs[1] alone: reference algorithm on PyTorch-CPU, a bounded slice of query rows of one pair."""
     import torch
@@ -712,6 +758,11 @@ def main():
                 line["conv_error_vs_fp64"] = chk
             except Exception as e:  # noqa: BLE001 -- a diagnostic, never the reason a bench line is lost
                 line["conv_error_vs_fp64"] = {"error": repr(e)}
+            # what the step is bound by, read off the part itself (outside the timed region): socket power and shader clock sampled by
+            # rocm-smi while the same step runs back to back for a few seconds.  The dominant convolution family sits at the socket's
+            # power cap; the whole step averages a little under it.  Never the reason a bench line is lost.
+            if not args.no_alt:
+                line["power_probe"] = power_probe(restore_step, sync, it)
             if not args.no_alt:
                 # the same step on the other arithmetics (outside the timed region of `value`): strict fp32-MFMA convolutions +
                 # exact fp32 correlation sweep (no 16-bit pipe anywhere), and the bf16 x 3 convolution flavour
