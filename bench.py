@@ -540,6 +540,10 @@ def main():
         return dt, kern, out
 
     def finish(line):
+        try:   # peak of torch's allocator on this rank (inputs, weights, activations and the correlation's workspaces all live there)
+            line["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        except Exception:  # noqa: BLE001
+            pass
         if rank == 0:
             print(json.dumps(line))
         if dist is not None:
