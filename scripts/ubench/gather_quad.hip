@@ -5,6 +5,9 @@
 // a window of `win` KiB per workgroup (L2-resident; larger than the CU's 32 KiB L1 unless win <= 16).
 //   mode 0  own segment per lane: instruction k of a group of 4 reads piece k of the lane's segment        (64 segments / instruction)
 //   mode 1  quad-shared: lane 4q+i reads piece i of segment (k, q)                                         (16 segments / instruction)
+//   mode 3  as 1, and every group of four instructions is followed by what bringing the pieces back to a one-segment-per-lane layout costs
+//           through LDS: 4 ds_write_b128 (piece (segment, i) -> [segment][i], 144-byte segment stride), a wait, 4 ds_read_b128 of the lane's
+//           own segment -- the transposition a DCNv2 forward with quad-shared gathers would need in front of its blend
 //   mode 2  as 0 with 32-byte segments split over lanes l and l+32 (the real kernel's two half-waves): instruction k reads piece k & 1 of
 //           the segment of (l & 31, l >> 5) ... i.e. own 32-byte run per lane, two instructions per run
 // build: hipcc --offload-arch=gfx950 -O3 -o gather_quad gather_quad.hip
@@ -18,6 +21,7 @@ __device__ __forceinline__ unsigned rnd(unsigned x) { x ^= x << 13; x ^= x >> 17
 template <int MODE>
 __global__ void __launch_bounds__(512) k(int n, const unsigned* __restrict__ buf, unsigned win_bytes, unsigned long long* __restrict__ clk, unsigned* __restrict__ out) {
   const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) unsigned char tr[8][64 * 144 + 64];   // per wave: 64 segments x (64 + 80 pad) bytes
   const char* base = reinterpret_cast<const char*>(buf) + (size_t)blockIdx.x * win_bytes;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)win_bytes, 0x00020000);
   const unsigned nseg = win_bytes / 64;
@@ -51,6 +55,14 @@ __global__ void __launch_bounds__(512) k(int n, const unsigned* __restrict__ buf
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) v[4 * g + kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[kk], 0, 0);
+      if (MODE == 3) {
+        // instruction kk, lane 4q+i holds piece i of segment 16kk+q -> LDS [16kk+q][i]; then lane l reads the four pieces of segment l
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<u32x4*>(&tr[w][(16 * kk + (l >> 2)) * 144 + (l & 3) * 16]) = v[4 * g + kk];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) v[4 * g + kk] = *reinterpret_cast<const u32x4*>(&tr[w][l * 144 + kk * 16]);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) sink ^= v[kk];
@@ -95,6 +107,7 @@ int main() {
     run<0>(2000, buf, clk, out, nwg, win);
     run<2>(2000, buf, clk, out, nwg, win);
     run<1>(2000, buf, clk, out, nwg, win);
+    run<3>(2000, buf, clk, out, nwg, win);
   }
   return 0;
 }
