@@ -218,6 +218,10 @@ def conv_rooflines(kern, fam, steps, pmc):
         if kid == "conv3x3_split":
             e["frac_of_sustained_rate"] = _rnd(_tf(execd, kms) / BF16_SUSTAINED_TFLOPS)
             e["sustained_tflops"] = {"changing_random_operands": BF16_SUSTAINED_TFLOPS, "constant_operands": BF16_SUSTAINED_CONST_OPERANDS_TFLOPS}
+            # what actually caps it, measured with rocm-smi while the body layer runs back to back (DESIGN.md 6.14,
+            # profiles/r06_power_and_clock_by_kernel.txt): the socket sits at its 1 400 W cap and the shader clock at 1.64 of 2.4 GHz --
+            # `peak` above assumes 2.4 GHz; the line's own `power_probe` reads the same two numbers over the whole step
+            e["limited_by"] = "socket power cap (1400 W) -> shader clock ~1.64 of 2.4 GHz while this family runs; see power_probe, DESIGN.md 6.14"
             # the family has TWO roofs: the matrix pipe at the rate it sustains on non-zero operands and HBM at
             # the ~6.3 TB/s it delivers; `sum` = what a kernel whose memory and matrix phases do not overlap at all would take
             if e["traffic"]:
