@@ -776,6 +776,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     // ----------------------------------------------------------------------------------------------------------------
     const int b = epi_tc.b, y0 = epi_tc.ty * THY, x0 = epi_tc.tx * TWX;
     tc_next(epi_tc);
+    // the lane's first output channel, re-read through an opaque move once per tile: left loop-invariant, hipcc hoists the generic path's
+    // sixteen residual / output base addresses (pointer + channel offset, 64-bit pairs) out of the tile loop and keeps them in 32 registers
+    // of the MFMA loop -- or spills them, and every reload in the epilogue then carries an s_waitcnt vmcnt(0) that drains the stores
+    int co_e = co_lane;
+    if constexpr (MODE == 0) asm volatile("" : "+v"(co_e));   // (the DCN head's quad stores measured 3 % slower with it)
     // Channels-last tiles WITH A RESIDUAL that lie inside the image with all their channels (every tile of the bodies' second convolutions
     // but the map's last row / column of tiles): a straight-line epilogue.  Row 0's eight residual pieces are requested HERE, in front of the
     // bias / activation arithmetic, row 1's before row 0 is stored.  (The generic path below fetches each piece behind its own branches
@@ -820,7 +825,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     if constexpr (EPI_FAST) {
       fast = (p.res1 != nullptr || p.res2 != nullptr) && p.out_vec4 != 0 && cb * MW + MW <= p.Cout && y0 + THY <= p.H && x0 + TWX <= p.W &&
              (FL != 1 || (p.io_flags & 14) == 0);   // (without a residual the generic path's stores measured 1 % faster)
-      fpix = (size_t)b * p.out_img_pitch + (size_t)(y0 + 2 * wv) * p.out_row_pitch + (size_t)(x0 + j) * p.out_pix_pitch + co_lane;
+      fpix = (size_t)b * p.out_img_pitch + (size_t)(y0 + 2 * wv) * p.out_row_pitch + (size_t)(x0 + j) * p.out_pix_pitch + co_e;
       if (fast && p.res1 != nullptr) res_load(p.res1, 0);
     }
 #pragma unroll
@@ -847,7 +852,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           for (int r = 0; r < 16; ++r) v[r & 3] += acc[mt][nt][r];
       const int y = y0 + 2 * wv, x = x0 + j;
       if (y < p.H && x < p.W) {
-        const size_t o = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co_lane;
+        const size_t o = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch + co_e;
         if constexpr (IO16) *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(p.out) + 2 * (o / 2)) = v;   // (stays inside a bf16 tensor)
         else *reinterpret_cast<f32x4*>(p.out + o) = v;
       }
@@ -866,7 +871,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
-            const int col = co_lane + mt * 32 + 8 * qd;   // channel inside this launch's slice
+            const int col = co_e + mt * 32 + 8 * qd;   // channel inside this launch's slice
             if constexpr (MODE == 5) {
               if (col - 4 * hi >= p.Cout) continue;       // (wave-uniform: the whole 8-channel group lies beyond the slice)
             } else {
@@ -911,7 +916,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
         // MaxPool2d(2, 2): rows 2wv, 2wv+1 are the two accumulator sets of this lane, the horizontal neighbour is lane j ^ 1
         const int yo = (y0 >> 1) + wv, xo = (x0 + j) >> 1;
         const bool pok = (y0 + 2 * wv + 1) < p.H && (x0 + j) < p.W && (j & 1) == 0;
-        float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)yo * p.out_row_pitch + (size_t)xo * p.out_pix_pitch + co_lane;
+        float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)yo * p.out_row_pitch + (size_t)xo * p.out_pix_pitch + co_e;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -922,7 +927,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               const float m = fmaxf(acc[mt][0][4 * qd + e], acc[mt][1][4 * qd + e]);
               v[e] = fmaxf(m, __shfl_xor(m, 1, 64));
             }
-            if (pok && co_lane + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
+            if (pok && co_e + mt * 32 + 8 * qd + 3 < p.Cout) *reinterpret_cast<f32x4*>(ob + mt * 32 + 8 * qd) = v;
           }
       } else if (EPI_FAST && fast) {
         static_assert(NT == 2, "two pixel rows per wave");
@@ -955,7 +960,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           if (!pok) continue;
           if constexpr (MODE == 0) {
             const size_t opix = (size_t)b * p.out_img_pitch + (size_t)y * p.out_row_pitch + (size_t)x * p.out_pix_pitch;
-            float* ob = p.out + opix + co_lane;
+            float* ob = p.out + opix + co_e;
             if constexpr (FL == 1) {
               if (p.io_flags & 2) {
                 // bf16 output (Cout % 8 == 0): lanes j and j + 32 hold channels 8qd + 0..3 / 8qd + 4..7 of the same pixel;
@@ -1007,7 +1012,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
               for (int qd = 0; qd < 4; ++qd) {
-                const int co = co_lane + mt * 32 + 8 * qd;
+                const int co = co_e + mt * 32 + 8 * qd;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
@@ -1062,7 +1067,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           } else if constexpr (MODE == 1) {
             // PixelShuffle(2): channel 4*c2 + 2*dy + dx of pixel (y, x) -> channel c2 of pixel (2y + dy, 2x + dx)
             float* ob = p.out + (size_t)b * p.out_img_pitch + (size_t)(2 * y) * p.out_row_pitch +
-                        (size_t)(2 * x) * p.out_pix_pitch + (co_lane >> 2);
+                        (size_t)(2 * x) * p.out_pix_pitch + (co_e >> 2);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               if (cb * MW + mt * 32 + 32 <= p.Cout && p.out_vec4 && !(p.io_flags & C2M_IO_DWORD_STORES)) {
@@ -1082,7 +1087,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
               }
 #pragma unroll
               for (int qd = 0; qd < 4; ++qd)
-                if (co_lane + mt * 32 + 8 * qd < p.Cout) {
+                if (co_e + mt * 32 + 8 * qd < p.Cout) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
                     ob[(size_t)(e >> 1) * p.out_row_pitch + (size_t)(e & 1) * p.out_pix_pitch + mt * 8 + 2 * qd] = acc[mt][nt][4 * qd + e];
@@ -1102,18 +1107,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
                   const f32x4 t = quad_transpose(v, j);
-                  const int ch = co_lane + mt * 32 + 8 * qd + (j & 3);
+                  const int ch = co_e + mt * 32 + 8 * qd + (j & 3);
                   if (ch < p.Cout) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.Cout + ch) * HWs + (size_t)y * p.W + (x & ~3)) = t;
                 }
               continue;
             }
-            float* ob = p.out + ((size_t)b * p.Cout + co_lane) * HWs + (size_t)y * p.W + x;
+            float* ob = p.out + ((size_t)b * p.Cout + co_e) * HWs + (size_t)y * p.W + x;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int cr = mt * 32 + 8 * (r >> 2) + (r & 3);
-                if (co_lane + cr < p.Cout) ob[(size_t)cr * HWs] = acc[mt][nt][r];
+                if (co_e + cr < p.Cout) ob[(size_t)cr * HWs] = acc[mt][nt][r];
               }
           }
         }
