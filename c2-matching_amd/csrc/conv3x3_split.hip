@@ -781,8 +781,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
     // of the MFMA loop -- or spills them, and every reload in the epilogue then carries an s_waitcnt vmcnt(0) that drains the stores
     int co_e = co_lane;
     if constexpr (MODE == 0) asm volatile("" : "+v"(co_e));   // (the DCN head's quad stores measured 3 % slower with it)
-    // Channels-last tiles WITH A RESIDUAL that lie inside the image with all their channels (every tile of the bodies' second convolutions
-    // but the map's last row / column of tiles): a straight-line epilogue.  Row 0's eight residual pieces are requested HERE, in front of the
+    // Channels-last tiles that lie inside the image with all their channels (every tile of the 64 -> 64 bodies but the map's last row /
+    // column of tiles): a straight-line epilogue.  Row 0's eight residual pieces are requested HERE, in front of the
     // bias / activation arithmetic, row 1's before row 0 is stored.  (The generic path below fetches each piece behind its own branches
     // and between two stores that may alias it: hipcc serialises that into 16 x (load, s_waitcnt vmcnt(0), add, store), and on gfx9 that
     // wait also drains the previous store -- 21 000 cycles per tile against 7 300 without a residual, scripts/trace_split.py.)
@@ -823,8 +823,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
       }
     }
     if constexpr (EPI_FAST) {
-      fast = (p.res1 != nullptr || p.res2 != nullptr) && p.out_vec4 != 0 && cb * MW + MW <= p.Cout && y0 + THY <= p.H && x0 + TWX <= p.W &&
-             (FL != 1 || (p.io_flags & 14) == 0);   // (without a residual the generic path's stores measured 1 % faster)
+      fast = p.out_vec4 != 0 && cb * MW + MW <= p.Cout && y0 + THY <= p.H && x0 + TWX <= p.W && (FL != 1 || (p.io_flags & 14) == 0);
       fpix = (size_t)b * p.out_img_pitch + (size_t)(y0 + 2 * wv) * p.out_row_pitch + (size_t)(x0 + j) * p.out_pix_pitch + co_e;
       if (fast && p.res1 != nullptr) res_load(p.res1, 0);
     }
@@ -950,7 +949,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(Params p) {
           res_load(p.res2, 1);
         }
         store_row(0);
-        res_add(1);
+        if (p.res1 != nullptr || p.res2 != nullptr) res_add(1);
         store_row(1);
       } else {
 #pragma unroll

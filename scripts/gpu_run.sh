@@ -130,6 +130,8 @@ for stage in "$@"; do
     ab_epi16)   (timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_restoration_gpu.py -m gpu -q -x -k "bf16 or io16 or cfg5 or autocast" 2>&1 | tail -5) > $O/ab_epi16_tests.log 2>&1
                 (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --io16 --batch 4 --only "@1280" --iters 20 2>&1 | grep "^{'layer"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --io16 --only "64->64 @640" --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_epi16_layers.log 2>&1
                 (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --lr 320 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_epi16_step.log 2>&1 ;;
+    ab_lib)     (for lib in "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_lib_layers.log 2>&1
+                (for lib in "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_lib_step.log 2>&1 ;;
     prof_cfg5)  cd /tmp
                 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
                 cp $(find $O/prof_cfg5 -name '*kernel_stats.csv' | head -1) $O/cfg5_kernel_stats.csv; rm -rf $O/prof_cfg5
