@@ -769,7 +769,7 @@ def main():
             # what the step is bound by, read off the part itself (outside the timed region): socket power and shader clock sampled by
             # rocm-smi while the same step runs back to back for a few seconds.  The dominant convolution family sits at the socket's
             # power cap; the whole step averages a little under it.  Never the reason a bench line is lost.
-            if not args.no_alt:
+            if not args.no_alt and world == 1 and rank == 0:   # (one process only: rocm-smi lists every card, the parser reads the first)
                 line["power_probe"] = power_probe(restore_step, sync, it)
             if not args.no_alt:
                 # the same step on the other arithmetics (outside the timed region of `value`): strict fp32-MFMA convolutions +
