@@ -132,6 +132,10 @@ for stage in "$@"; do
                 (for lib in "" $R/build_exp/nomix/libc2m_hip.so "" $R/build_exp/nomix/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --lr 320 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_epi16_step.log 2>&1 ;;
     ab_lib)     (for lib in "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 300 python scripts/bench_conv.py --algo split16 --iters 20 2>&1 | grep "^{'layer"; done) > $O/ab_lib_layers.log 2>&1
                 (for lib in "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so "" $R/build_exp/${AB_LIB:-fastall}/libc2m_hip.so; do echo "=== C2M_LIB=$lib"; C2M_LIB=$lib timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>&1 | grep "^{" | cut -c1-700; done) > $O/ab_lib_step.log 2>&1 ;;
+    power3)     (for abl in 0 1 6 8 32 64 39 47 48; do
+                   echo "=== time C2M_SPLIT_ABL=$abl"; C2M_SPLIT_ABL=$abl timeout 200 python scripts/bench_conv.py --algo split16 --only "body 64->64 @640" --iters 20 2>&1 | grep "^{'layer"
+                   C2M_SPLIT_ABL=$abl bash scripts/power_probe.sh "python $R/scripts/bench_conv.py --algo split16 --iters 5000 --only 'body 64->64 @640'" "power C2M_SPLIT_ABL=$abl (1 no weight DMA, 2 no halo loads, 4 no split, 8 no unit-end waits / barriers, 16 no MFMAs, 32 no operand reads, 64 one store per tile)" 8
+                 done) > $O/power_probe3.log 2>&1 ;;
     prof_cfg5)  cd /tmp
                 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_cfg5 -o step -- python $R/bench.py --lr 320 --dtype bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_cfg5.log 2>&1
                 cp $(find $O/prof_cfg5 -name '*kernel_stats.csv' | head -1) $O/cfg5_kernel_stats.csv; rm -rf $O/prof_cfg5
