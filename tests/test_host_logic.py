@@ -152,6 +152,45 @@ def test_bench_flop_model_matches_kernel_tiling():
     assert bench.corr_executed_flops(B, C, h) == want == 9286793035776
 
 
+def test_bench_power_probe_parses_rocm_smi_and_never_raises(monkeypatch, tmp_path):
+    """bench.py's `power_probe` (socket power / shader clock while the step runs back to back): the rocm-smi JSON is parsed as the tool
+    prints it on the MI355X boxes, idle samples (< 600 W) are dropped when busy ones exist, and an unreadable tool yields {"error": ...}
+    instead of an exception -- the probe must never cost a bench line."""
+    import importlib.util
+    import os
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr("shutil.which", lambda name: str(fake))
+    seq = iter([(241.0, 95), (1398.0, 1641), (1402.0, 1650), (1400.0, 1633)] + [(1400.0, 1640)] * 1000)
+
+    class R:
+        def __init__(self, out):
+            self.stdout = out
+
+    def run_ok(cmd, **kw):
+        if "-M" in cmd:
+            return R('WARNING: something\n{"card0": {"Max Graphics Package Power (W)": "1400.0"}}')
+        w, c = next(seq)
+        return R('{"card0": {"sclk clock speed:": "(%dMhz)", "sclk clock level:": "1", "Current Socket Graphics Package Power (W)": "%.1f"}}' % (c, w))
+    monkeypatch.setattr(subprocess, "run", run_ok)
+    it = [0]
+    got = bench.power_probe(lambda: time.sleep(0.01), lambda: None, it, seconds=0.3)
+    assert got["cap_w"] == 1400.0 and 1390 <= got["socket_w"] <= 1402 and 1600 <= got["sclk_mhz"] <= 1700 and got["samples"] >= 3, got
+
+    def run_bad(cmd, **kw):
+        raise OSError("no such tool")
+    monkeypatch.setattr(subprocess, "run", run_bad)
+    got = bench.power_probe(lambda: time.sleep(0.01), lambda: None, it, seconds=0.1)
+    assert "error" in got, got
+
+
 def test_bench_dcn_roofline_prices_both_gemm_arithmetics():
     """bench.py's DCNv2 rows: the fp32 GEMM executes the algorithmic flops on the fp32 matrix pipe; the f16 x 2 GEMM executes
     three products per k step on the f16 pipe -- `frac` is always executed / that pipe's dense peak, and `frac_vs_fp32_pipe`
